@@ -1,0 +1,52 @@
+"""Builds dmesh_renderer_amd/libdmesh_renderer_hip.so (gfx950 only) with hipcc, in-tree.
+
+    python -m dmesh_renderer_amd.build [--force]
+
+hipcc cross-compiles gfx950 without a GPU.  -ffp-contract=off is part of the product's
+FP contract (see csrc/dmr_device.hpp), not a debugging flag.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdmesh_renderer_hip.so")
+SOURCES = ["dmr_api.hip", "dmr_binning.hip", "dmr_tri.hip", "dmr_tet.hip"]
+HEADERS = ["dmr_device.hpp", "dmr_kernels.hpp", os.path.join("..", "..", "include", "dmesh_renderer_amd.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB + ".tmp"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,321 @@
+// dmr_api.hip -- C ABI (include/dmesh_renderer_amd.h) and host orchestration.
+//
+// Replaces the host side of Rasterizer::forward/backward (cuda_rasterizer/rasterizer_impl.cu:175-467)
+// and Renderer::forward/backward (cuda_renderer/renderer_impl.cu:193-498): scratch carving,
+// stage sequencing, the single device->host read of num_rendered.  Unlike the reference
+// (a cudaDeviceSynchronize after every stage on the legacy default stream, Q14) everything is
+// enqueued on the caller's stream and the only host wait is that 4-byte read, which sizes the
+// binning buffer.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "dmr_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& m) { g_err = m; return 1; }
+
+#define DMR_HIP(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t n) { return (n + ALIGN - 1) & ~(ALIGN - 1); }
+
+// Bump carving of a scratch buffer (the reference's obtain(), rasterizer_impl.h:10-16).
+struct Carver {
+    char* base; size_t off;
+    explicit Carver(void* b) : base(reinterpret_cast<char*>(b)), off(0) {}
+    template <class T> T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += up(count * sizeof(T));
+        return p;
+    }
+};
+
+struct PointState { float4* vproj; };
+struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* tiles_touched; };
+struct ImageState {
+    uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_cursor; int* num_rendered;
+    float* final_T; float* final_prev_T; uint32_t* n_contrib;
+    int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
+};
+struct BinningState { uint64_t* keys; uint32_t* face_list; };
+
+size_t carve_point(void* b, size_t BP, PointState& s) { Carver c(b); s.vproj = c.take<float4>(BP); return c.off; }
+size_t carve_face(void* b, size_t BF, bool tet, FaceState& s) {
+    Carver c(b);
+    s.rect = c.take<uint2>(BF); s.key_depth = c.take<float>(BF);
+    s.max_depth = tet ? c.take<float>(BF) : nullptr;
+    s.tiles_touched = c.take<uint32_t>(BF);
+    return c.off;
+}
+size_t carve_image(void* b, size_t ntiles, size_t npix, bool tet, ImageState& s) {
+    Carver c(b);
+    s.tile_count = c.take<uint32_t>(ntiles); s.tile_offset = c.take<uint32_t>(ntiles + 1);
+    s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(1);
+    s.final_T = c.take<float>(npix); s.final_prev_T = c.take<float>(npix); s.n_contrib = c.take<uint32_t>(npix);
+    if (tet) {
+        s.first_face = c.take<int32_t>(npix); s.first_tet = c.take<int32_t>(npix);
+        s.last_face = c.take<int32_t>(npix); s.last_tet = c.take<int32_t>(npix);
+        s.is_active = c.take<uint8_t>(npix);
+    } else {
+        s.first_face = s.first_tet = s.last_face = s.last_tet = nullptr; s.is_active = nullptr;
+    }
+    return c.off;
+}
+size_t carve_binning(void* b, size_t R, BinningState& s) {
+    Carver c(b);
+    s.keys = c.take<uint64_t>(R); s.face_list = c.take<uint32_t>(R);
+    return c.off;
+}
+
+struct Dims { int gx, gy, r0, r1, ntiles; size_t BP, BF, npix; };
+
+int check_scene(const dmr_scene* s, bool tet, Dims& d) {
+    if (!s) return fail("null scene");
+    if (s->B <= 0 || s->W <= 0 || s->H <= 0 || s->P < 0 || s->F < 0 || s->T < 0) return fail("bad dimensions");
+    if ((int64_t)s->B * s->P > INT32_MAX || (int64_t)s->B * s->F > INT32_MAX || (int64_t)s->B * s->W * s->H > INT32_MAX)
+        return fail("problem too large for 32-bit indexing");
+    d.gx = (s->W + dmr::TILE - 1) / dmr::TILE;
+    d.gy = (s->H + dmr::TILE - 1) / dmr::TILE;
+    if (d.gx > 65535 || d.gy > 65535) return fail("image too large (tile coordinates must fit 16 bits)");
+    d.r0 = s->row_begin; d.r1 = s->row_end;
+    if (d.r0 == 0 && d.r1 == 0) d.r1 = d.gy;
+    d.r0 = std::max(0, std::min(d.gy, d.r0));
+    d.r1 = std::max(d.r0, std::min(d.gy, d.r1));
+    d.ntiles = s->B * d.gx * d.gy;
+    d.BP = (size_t)s->B * s->P; d.BF = (size_t)s->B * s->F; d.npix = (size_t)s->B * s->W * s->H;
+    if (tet && s->ray_random_seed > 0)
+        return fail("ray_random_seed > 0 (cuRAND XORWOW jitter, cuda_renderer/forward.cu:82-88) is not implemented: parity unpinned");
+    if (tet && s->F > 0 && s->P > 0 && (!s->tets || !s->face_tets || !s->tet_faces)) return fail("tet topology missing");
+    return 0;
+}
+
+// pinned landing pad for the num_rendered read, one per host thread
+int* pinned_slot() {
+    thread_local int* slot = nullptr;
+    if (!slot) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&slot), 64, hipHostMallocDefault) != hipSuccess) slot = nullptr;
+    }
+    return slot;
+}
+
+// stages shared by both renderers up to the sorted per-tile lists
+int run_binning(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc, void* ctx, hipStream_t st,
+                PointState& ps, FaceState& fs, ImageState& is, BinningState& bs, int* num_rendered) {
+    PointState tp; FaceState tf; ImageState ti;
+    void* pb = alloc(ctx, DMR_BUF_POINT, carve_point(nullptr, d.BP, tp));
+    void* fb = alloc(ctx, DMR_BUF_FACE, carve_face(nullptr, d.BF, tet, tf));
+    void* ib = alloc(ctx, DMR_BUF_IMAGE, carve_image(nullptr, (size_t)d.ntiles, d.npix, tet, ti));
+    if (!pb || !fb || !ib) return fail("scratch allocation failed");
+    carve_point(pb, d.BP, ps);
+    carve_face(fb, d.BF, tet, fs);
+    carve_image(ib, (size_t)d.ntiles, d.npix, tet, is);
+
+    DMR_HIP(hipMemsetAsync(is.tile_count, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
+    dmr::launch_project_verts(*s, ps.vproj, st);
+    dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
+                            fs.tiles_touched, is.tile_count, st);
+    dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, st);
+    int* host_R = pinned_slot();
+    if (!host_R) return fail("hipHostMalloc failed");
+    DMR_HIP(hipMemcpyAsync(host_R, is.num_rendered, sizeof(int), hipMemcpyDeviceToHost, st));
+    DMR_HIP(hipStreamSynchronize(st));  // the one host wait of the forward pass (rasterizer_impl.cu:287-292)
+    const int R = *host_R;
+    if (R < 0) return fail("num_rendered overflows 31 bits");
+    *num_rendered = R;
+
+    BinningState tb;
+    void* bb = alloc(ctx, DMR_BUF_BINNING, carve_binning(nullptr, (size_t)R, tb));
+    if (!bb && R > 0) return fail("binning allocation failed");
+    carve_binning(bb, (size_t)R, bs);
+    if (R > 0) {
+        dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
+                                  (uint32_t)R, st);
+        dmr::launch_sort_tiles(d.ntiles, is.tile_offset, bs.keys, bs.face_list, st);
+    }
+    DMR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dmr_last_error(void) { return g_err.c_str(); }
+int dmr_abi_version(void) { return DMR_ABI_VERSION; }
+const char* dmr_build_arch(void) { return "gfx950"; }
+
+int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_alloc_fn alloc, void* ctx,
+                    void* stream, int* num_rendered) {
+    Dims d;
+    if (check_scene(s, false, d)) return 1;
+    if (!alloc || !num_rendered || !out_color || !out_depth) return fail("null argument");
+    *num_rendered = 0;
+    if (s->P == 0 || s->F == 0) return 0;  // render.cu:105 (and Q16: F == 0)
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PointState ps; FaceState fs; ImageState is; BinningState bs;
+    if (run_binning(s, false, d, alloc, ctx, st, ps, fs, is, bs, num_rendered)) return 1;
+    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib};
+    dmr::launch_tri_forward(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
+                            out_depth, st);
+    DMR_HIP(hipGetLastError());
+    return 0;
+}
+
+int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL_ddepth, int num_rendered,
+                     const void* point_buf, const void* face_buf, const void* binning_buf, const void* image_buf,
+                     float* dL_dverts, float* dL_dvcolor, float* dL_dfopacity, float* dL_dvdepth, float* dL_dfintense,
+                     dmr_alloc_fn alloc, void* ctx, void* stream) {
+    Dims d;
+    if (check_scene(s, false, d)) return 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (s->P == 0 || s->F == 0 || num_rendered <= 0) {  // render.cu:173: gradients are all zero
+        if (s->P > 0) {
+            DMR_HIP(hipMemsetAsync(dL_dverts, 0, sizeof(float) * 3 * (size_t)s->P, st));
+            DMR_HIP(hipMemsetAsync(dL_dvcolor, 0, sizeof(float) * 3 * (size_t)s->P, st));
+            DMR_HIP(hipMemsetAsync(dL_dvdepth, 0, sizeof(float) * d.BP, st));
+        }
+        if (s->F > 0) {
+            DMR_HIP(hipMemsetAsync(dL_dfopacity, 0, sizeof(float) * (size_t)s->F, st));
+            DMR_HIP(hipMemsetAsync(dL_dfintense, 0, sizeof(float) * d.BF, st));
+        }
+        return 0;
+    }
+    if (!point_buf || !face_buf || !binning_buf || !image_buf || !alloc) return fail("null scratch buffer");
+    PointState ps; FaceState fs; ImageState is; BinningState bs;
+    carve_point(const_cast<void*>(point_buf), d.BP, ps);
+    carve_face(const_cast<void*>(face_buf), d.BF, false, fs);
+    carve_image(const_cast<void*>(image_buf), (size_t)d.ntiles, d.npix, false, is);
+    carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, bs);
+
+    const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
+    char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes));
+    if (!work) return fail("workspace allocation failed");
+    float* vrow = reinterpret_cast<float*>(work);
+    float* frow = reinterpret_cast<float*>(work + vbytes);
+    DMR_HIP(hipMemsetAsync(work, 0, vbytes + fbytes, st));
+    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib};
+    dmr::launch_tri_backward(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, dL_dcolor,
+                             dL_ddepth, vrow, frow, st);
+    dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
+    DMR_HIP(hipGetLastError());
+    return 0;
+}
+
+int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, float* out_active, dmr_alloc_fn alloc,
+                    void* ctx, void* stream, int* num_rendered) {
+    Dims d;
+    if (check_scene(s, true, d)) return 1;
+    if (!alloc || !num_rendered || !out_color || !out_depth || !out_active) return fail("null argument");
+    *num_rendered = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PointState ps; FaceState fs; ImageState is; BinningState bs;
+    if (run_binning(s, true, d, alloc, ctx, st, ps, fs, is, bs, num_rendered)) return 1;
+    dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
+                           is.last_face, is.last_tet, is.is_active};
+    dmr::launch_tet_first_intersect(*s, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
+                                    bs.face_list, img, st);
+    dmr::launch_tet_forward(*s, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
+    DMR_HIP(hipGetLastError());
+    return 0;
+}
+
+int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL_ddepth, const void* point_buf,
+                     const void* face_buf, const void* binning_buf, const void* image_buf, float* dL_dvcolor,
+                     float* dL_dfopacity, dmr_alloc_fn alloc, void* ctx, void* stream) {
+    Dims d;
+    if (check_scene(s, true, d)) return 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (s->P > 0) DMR_HIP(hipMemsetAsync(dL_dvcolor, 0, sizeof(float) * 3 * (size_t)s->P, st));
+    if (s->F > 0) DMR_HIP(hipMemsetAsync(dL_dfopacity, 0, sizeof(float) * (size_t)s->F, st));
+    if (s->P == 0 || s->F == 0) return 0;
+    if (!image_buf) return fail("null scratch buffer");
+    ImageState is;
+    carve_image(const_cast<void*>(image_buf), (size_t)d.ntiles, d.npix, true, is);
+    dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
+                           is.last_face, is.last_tet, is.is_active};
+    dmr::launch_tet_backward(*s, d.gx, d.gy, d.r0, d.r1, img, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, st);
+    DMR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- parity/debug export ---------------------------------------------------------------------
+namespace {
+__global__ void k_export_vproj(const float4* v, int64_t n, int what, float* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (what == 0) { dst[2 * i] = v[i].x; dst[2 * i + 1] = v[i].y; }
+    else dst[i] = v[i].z;
+}
+__global__ void k_export_ranges(const uint32_t* off, const uint32_t* cnt, int64_t n, uint32_t* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // the reference leaves empty tiles at (0, 0) (cudaMemset, rasterizer_impl.cu:330)
+    const bool empty = cnt[i] == 0;
+    dst[2 * i] = empty ? 0u : off[i];
+    dst[2 * i + 1] = empty ? 0u : off[i + 1];
+}
+}  // namespace
+
+int64_t dmr_export(const dmr_scene* s, int is_tet, int num_rendered, const char* name, const void* point_buf,
+                   const void* face_buf, const void* binning_buf, const void* image_buf, void* dst, int64_t cap,
+                   void* stream) {
+    Dims d;
+    if (!name || check_scene(s, is_tet != 0, d)) return -1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PointState ps; FaceState fs; ImageState is; BinningState bs;
+    carve_point(const_cast<void*>(point_buf), d.BP, ps);
+    carve_face(const_cast<void*>(face_buf), d.BF, is_tet != 0, fs);
+    carve_image(const_cast<void*>(image_buf), (size_t)d.ntiles, d.npix, is_tet != 0, is);
+    carve_binning(const_cast<void*>(binning_buf), (size_t)std::max(0, num_rendered), bs);
+    const std::string n(name);
+    auto plain = [&](const void* src, size_t bytes) -> int64_t {
+        if (dst && src && bytes) {
+            if (hipMemcpyAsync(dst, src, std::min<size_t>(bytes, (size_t)cap), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                g_err = "export copy failed";
+                return -1;
+            }
+        }
+        return (int64_t)bytes;
+    };
+    if (n == "image" || n == "ndc_z") {
+        const size_t bytes = d.BP * (n == "image" ? 8 : 4);
+        if (dst && d.BP && (size_t)cap >= bytes)
+            k_export_vproj<<<dim3((unsigned)((d.BP + 255) / 256)), dim3(256), 0, st>>>(
+                ps.vproj, (int64_t)d.BP, n == "image" ? 0 : 1, reinterpret_cast<float*>(dst));
+        return (int64_t)bytes;
+    }
+    if (n == "ranges") {
+        const size_t bytes = (size_t)d.ntiles * 8;
+        if (dst && (size_t)cap >= bytes)
+            k_export_ranges<<<dim3((unsigned)((d.ntiles + 255) / 256)), dim3(256), 0, st>>>(
+                is.tile_offset, is.tile_count, d.ntiles, reinterpret_cast<uint32_t*>(dst));
+        return (int64_t)bytes;
+    }
+    if (n == "key_depth") return plain(fs.key_depth, d.BF * 4);
+    if (n == "max_depth") return is_tet ? plain(fs.max_depth, d.BF * 4) : -1;
+    if (n == "tiles_touched") return plain(fs.tiles_touched, d.BF * 4);
+    if (n == "face_list") return plain(bs.face_list, (size_t)std::max(0, num_rendered) * 4);
+    if (n == "final_T") return plain(is.final_T, d.npix * 4);
+    if (n == "final_prev_T") return plain(is.final_prev_T, d.npix * 4);
+    if (n == "n_contrib") return plain(is.n_contrib, d.npix * 4);
+    if (is_tet) {
+        if (n == "first_face") return plain(is.first_face, d.npix * 4);
+        if (n == "first_tet") return plain(is.first_tet, d.npix * 4);
+        if (n == "last_face") return plain(is.last_face, d.npix * 4);
+        if (n == "last_tet") return plain(is.last_tet, d.npix * 4);
+        if (n == "is_active") return plain(is.is_active, d.npix);
+    }
+    g_err = "unknown export item: " + n;
+    return -1;
+}
+
+}  // extern "C"

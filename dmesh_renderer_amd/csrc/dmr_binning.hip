@@ -1,0 +1,250 @@
+// dmr_binning.hip -- projection, tile binning and per-tile depth sort (gfx950).
+//
+// Replaces, for both renderers:
+//   preprocessPointCUDA   cuda_rasterizer/forward.cu:17-47   (cuda_renderer/forward.cu:21-52)
+//   preprocessFaceCUDA    cuda_rasterizer/forward.cu:76-149  (cuda_renderer/forward.cu:178-260)
+//   cub InclusiveSum + duplicateWithKeys + cub SortPairs + identifyTileRanges
+//                         cuda_rasterizer/rasterizer_impl.cu:44-124,278-338
+//
+// The reference emits one (tile<<32 | depth_bits, face) pair per touched tile and runs
+// ONE global 64-bit radix sort over all R pairs (k = ceil((32+bit)/8) passes, ~24 B per
+// pair per pass).  Here the tile is known at emission time, so pairs are counted and
+// scattered straight into their tile's segment (counting sort on the tile digit) and
+// each segment is then sorted by (depth_bits, face_id) inside LDS by one workgroup.
+// Within a (view, tile) a face occurs at most once, so (depth_bits, face_id) is a total
+// order and equals the order of the reference's STABLE sort, whose ties keep emission
+// order = ascending face id (Q6).  The result -- per-tile face lists and ranges -- is
+// bit-identical to the reference's sorted list, whatever order the scatter ran in.
+#include "dmr_kernels.hpp"
+
+namespace dmr {
+
+// ---------------------------------------------------------------------------
+// 1. per (view, vertex): pixel coordinates, NDC z and the per-view depth attribute packed
+//    into one 16-byte record so later stages gather a vertex with a single dwordx4 load.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_project_verts(int B, int P, const float* __restrict__ verts, const float* __restrict__ mv_mats,
+                const float* __restrict__ proj_mats, const float* __restrict__ verts_depth,
+                int W, int H, float4* __restrict__ vproj) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * P) return;
+    const int b = (int)(idx / P), p = (int)(idx % P);
+    const float* mv = mv_mats + 16 * b;
+    const float* pr = proj_mats + 16 * b;
+    V3 pv = xform4x3(load_v3(verts, p), mv);
+    V4 pc = xform4x4(pv, pr);
+    float p_w = (float)(1.0 / (double)clamp_w(pc.w));  // double divide (forward.cu:38)
+    V3 n = {pc.x * p_w, pc.y * p_w, pc.z * p_w};
+    vproj[idx] = make_float4(ndc2pix(n.x, W), ndc2pix(n.y, H), n.z, verts_depth[idx]);
+}
+
+// ---------------------------------------------------------------------------
+// 2. per (view, face): cull, tile rect, sort depth; count the face into every tile of its rect.
+//    rect is kept (packed 4 x u16) so the scatter pass does not redo the float work.
+// ---------------------------------------------------------------------------
+template <bool TET>
+__global__ void __launch_bounds__(256)
+k_setup_faces(int B, int P, int F, const int* __restrict__ faces, const float4* __restrict__ vproj,
+              int gx, int gy, int r0, int r1,
+              uint2* __restrict__ face_rect, float* __restrict__ key_depth, float* __restrict__ max_depth,
+              uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * F) return;
+    const int b = (int)(idx / F), f = (int)(idx % F);
+    const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
+    const float4 a0 = vproj[(int64_t)b * P + v0], a1 = vproj[(int64_t)b * P + v1], a2 = vproj[(int64_t)b * P + v2];
+    float max_z = a0.z, min_z = a0.z, depth = 0.0f;
+    depth += a0.z;
+    max_z = fmaxf(max_z, a1.z); min_z = fminf(min_z, a1.z); depth += a1.z;
+    max_z = fmaxf(max_z, a2.z); min_z = fminf(min_z, a2.z); depth += a2.z;
+    depth = depth / 3.0f;
+    uint32_t touched = 0;
+    Rect r = {0, 0, 0, 0};
+    if (!(max_z < -1.0f || min_z > 1.0f)) {
+        r = tile_rect({a0.x, a0.y}, {a1.x, a1.y}, {a2.x, a2.y}, gx, gy, r0, r1);
+        touched = (r.maxy - r.miny) * (r.maxx - r.minx);
+    }
+    if (touched == 0) r = {0, 0, 0, 0};
+    auto map01 = [](float z) { float d = (z + 1.0f) * 0.5f; if (d < 0.0f) d = 0.0f; if (d > 1.0f) d = 1.0f; return d; };
+    tiles_touched[idx] = touched;
+    face_rect[idx] = make_uint2(r.minx | (r.miny << 16), r.maxx | (r.maxy << 16));
+    // sort depth: tri = mean z (forward.cu:146-148), tet = min z (renderer_impl.cu:325); 0 when culled
+    key_depth[idx] = touched ? (TET ? map01(min_z) : map01(depth)) : 0.0f;
+    if (TET) max_depth[idx] = touched ? map01(max_z) : 0.0f;
+    if (touched) {
+        uint32_t* cnt = tile_count + (size_t)b * gx * gy;
+        for (uint32_t y = r.miny; y < r.maxy; y++)
+            for (uint32_t x = r.minx; x < r.maxx; x++) atomicAdd(&cnt[y * gx + x], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3. exclusive scan of the per-tile counts -> segment starts (= the reference's `ranges`),
+//    cursor copy for the scatter, and R.  One workgroup: n = B * tiles is small (C4: 8160).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+             uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + 1023) / 1024;
+    const int begin = min(n, tid * per), end = min(n, begin + per);
+    uint32_t local = 0;
+    for (int i = begin; i < end; i++) local += tile_count[i];
+    // inclusive wave scan
+    uint32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int w = 0; w < 16; w++) { uint32_t t = wave_sum[w]; wave_sum[w] = acc; acc += t; }
+        carry_s = acc;
+    }
+    __syncthreads();
+    uint32_t run = wave_sum[wave] + incl - local;
+    for (int i = begin; i < end; i++) {
+        tile_offset[i] = run;
+        tile_cursor[i] = run;
+        run += tile_count[i];
+    }
+    if (tid == 0) { tile_offset[n] = carry_s; *num_rendered = (int)carry_s; }
+}
+
+// ---------------------------------------------------------------------------
+// 4. scatter every (face, tile) pair into its tile's segment: key = depth_bits << 32 | face_id
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_scatter_faces(int B, int F, int gx, int gy, const uint2* __restrict__ face_rect,
+                const float* __restrict__ key_depth, const uint32_t* __restrict__ tiles_touched,
+                uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys, uint32_t capacity) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * F) return;
+    if (tiles_touched[idx] == 0) return;  // Q25: a culled face emits nothing
+    const int b = (int)(idx / F), f = (int)(idx % F);
+    const uint2 rr = face_rect[idx];
+    const uint32_t minx = rr.x & 0xffffu, miny = rr.x >> 16, maxx = rr.y & 0xffffu, maxy = rr.y >> 16;
+    const uint64_t key = ((uint64_t)__float_as_uint(key_depth[idx]) << 32) | (uint32_t)f;
+    uint32_t* cur = tile_cursor + (size_t)b * gx * gy;
+    for (uint32_t y = miny; y < maxy; y++)
+        for (uint32_t x = minx; x < maxx; x++) {
+            uint32_t slot = atomicAdd(&cur[y * gx + x], 1u);
+            if (slot < capacity) keys[slot] = key;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// 5. per-tile sort by (depth_bits, face_id).  One 256-thread workgroup per (view, tile).
+//    Normalised bitonic network (every compare-exchange ascending): with the segment
+//    virtually padded by +inf to a power of two, exchanges whose upper index is >= n are
+//    no-ops, so any n works without padding storage.  n <= SORT_LDS_KEYS runs in LDS;
+//    longer segments run the same network in place in global memory.
+// ---------------------------------------------------------------------------
+constexpr int SORT_LDS_KEYS = 4096;  // 32 KiB
+
+template <class Ptr>
+__device__ __forceinline__ void bitonic_pass(Ptr a, uint32_t n, uint32_t npow2, uint32_t tid, uint32_t nthreads, bool global_mem) {
+    for (uint32_t k = 2; k <= npow2; k <<= 1) {
+        // flip step: partner = i ^ (k - 1)
+        for (uint32_t t = tid; t < npow2 / 2; t += nthreads) {
+            uint32_t i = ((t & ~(k / 2 - 1)) << 1) | (t & (k / 2 - 1));
+            uint32_t l = i ^ (k - 1);
+            if (l < n) {
+                uint64_t x = a[i], y = a[l];
+                if (x > y) { a[i] = y; a[l] = x; }
+            }
+        }
+        if (global_mem) __threadfence_block();
+        __syncthreads();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < npow2 / 2; t += nthreads) {
+                uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                uint32_t l = i | j;
+                if (l < n) {
+                    uint64_t x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; }
+                }
+            }
+            if (global_mem) __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_tiles(const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ keys,
+             uint32_t* __restrict__ face_list) {
+    __shared__ uint64_t s_keys[SORT_LDS_KEYS];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
+    const uint32_t n = end - begin;
+    if (n == 0) return;
+    const uint32_t tid = threadIdx.x;
+    uint32_t npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    if (n <= SORT_LDS_KEYS) {
+        for (uint32_t i = tid; i < n; i += 256) s_keys[i] = keys[begin + i];
+        __syncthreads();
+        if (n > 1) bitonic_pass(s_keys, n, npow2, tid, 256, false);
+        for (uint32_t i = tid; i < n; i += 256) {
+            uint64_t k = s_keys[i];
+            keys[begin + i] = k;
+            face_list[begin + i] = (uint32_t)k;
+        }
+    } else {
+        uint64_t* g = keys + begin;
+        bitonic_pass(g, n, npow2, tid, 256, true);
+        for (uint32_t i = tid; i < n; i += 256) face_list[begin + i] = (uint32_t)g[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+void launch_project_verts(const dmr_scene& s, float4* vproj, hipStream_t st) {
+    const int64_t n = (int64_t)s.B * s.P;
+    if (n == 0) return;
+    k_project_verts<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
+        s.B, s.P, s.verts, s.mv_mats, s.proj_mats, s.verts_depth, s.W, s.H, vproj);
+}
+
+void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int gx, int gy, int r0, int r1,
+                        uint2* face_rect, float* key_depth, float* max_depth, uint32_t* tiles_touched,
+                        uint32_t* tile_count, hipStream_t st) {
+    const int64_t n = (int64_t)s.B * s.F;
+    if (n == 0) return;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (tet)
+        k_setup_faces<true><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect,
+                                                    key_depth, max_depth, tiles_touched, tile_count);
+    else
+        k_setup_faces<false><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect,
+                                                     key_depth, max_depth, tiles_touched, tile_count);
+}
+
+void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
+                       int* num_rendered, hipStream_t st) {
+    k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered);
+}
+
+void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
+                          const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
+                          hipStream_t st) {
+    const int64_t n = (int64_t)s.B * s.F;
+    if (n == 0) return;
+    k_scatter_faces<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
+        s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
+}
+
+void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, hipStream_t st) {
+    if (ntiles == 0) return;
+    k_sort_tiles<<<dim3((unsigned)ntiles), dim3(256), 0, st>>>(tile_offset, keys, face_list);
+}
+
+}  // namespace dmr

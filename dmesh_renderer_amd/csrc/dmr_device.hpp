@@ -1,0 +1,198 @@
+// dmr_device.hpp -- device helpers shared by the gfx950 kernels.
+//
+// FP contract: the whole library is compiled with -ffp-contract=off and every
+// expression below keeps the evaluation order of the reference helper it replaces,
+// so tile indices, sort keys and coverage are decided by the same float bits as in
+// the CPU oracle.  The double-precision islands of the reference (Q1 in SURVEY.md)
+// are kept.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmr {
+
+constexpr int TILE = 16;            // cuda_*/config.h:5-6 (BLOCK_X = BLOCK_Y = 16)
+constexpr int TILE_PIX = 256;
+constexpr float T_EPS = 0.0001f;    // auxiliary.h:8
+
+struct V2 { float x, y; };
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float b) { return {a.x * b, a.y * b, a.z * b}; }
+__device__ __forceinline__ V3 operator*(float b, V3 a) { return {b * a.x, b * a.y, b * a.z}; }
+__device__ __forceinline__ V3 operator/(V3 a, float b) { return {a.x / b, a.y / b, a.z / b}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// float -> int32, truncating, saturating, NaN -> 0 (v_cvt_i32_f32; same as CUDA's cvt.rzi)
+__device__ __forceinline__ int f2i(float v) { return __float2int_rz(v); }
+
+// auxiliary.h:33-36
+__device__ __forceinline__ float ndc2pix(float v, int S) {
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+// auxiliary.h:38-41
+__device__ __forceinline__ float pix2ndc(float v, int S) {
+    return (float)((((double)v * 2.0 + 1.0) / (double)S) - 1.0);
+}
+// auxiliary.h:245-253
+__device__ __forceinline__ float clamp_w(float w) {
+    const float eps = 1e-4f;
+    if (w >= 0 && w < eps) return eps;
+    else if (w < 0 && w > -eps) return -eps;
+    else return w;
+}
+// auxiliary.h:71-79
+__device__ __forceinline__ V3 xform4x3(V3 p, const float* __restrict__ m) {
+    return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+            m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+}
+// auxiliary.h:81-90
+__device__ __forceinline__ V4 xform4x4(V3 p, const float* __restrict__ m) {
+    return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+            m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+            m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]};
+}
+
+// Tile rect of a projected triangle, auxiliary.h:55-69 (truncate toward zero, clamp to
+// [0, grid]); rows additionally clipped to the band [r0, r1) of this shard.
+struct Rect { uint32_t minx, miny, maxx, maxy; };
+__device__ __forceinline__ Rect tile_rect(V2 p0, V2 p1, V2 p2, int gx, int gy, int r0, int r1) {
+    Rect r;
+    r.minx = (uint32_t)min(gx, max(0, f2i(fminf(fminf(p0.x, p1.x), p2.x) / (float)TILE)));
+    r.miny = (uint32_t)min(gy, max(0, f2i(fminf(fminf(p0.y, p1.y), p2.y) / (float)TILE)));
+    r.maxx = (uint32_t)min(gx, max(0, (int)((uint32_t)f2i(fmaxf(fmaxf(p0.x, p1.x), p2.x) / (float)TILE) + 1u)));
+    r.maxy = (uint32_t)min(gy, max(0, (int)((uint32_t)f2i(fmaxf(fmaxf(p0.y, p1.y), p2.y) / (float)TILE) + 1u)));
+    r.miny = max(r.miny, (uint32_t)r0);
+    r.maxy = min(r.maxy, (uint32_t)r1);
+    if (r.maxy < r.miny) r.maxy = r.miny;
+    return r;
+}
+
+// Per-pixel world-space ray, tri generateRaysCUDA (cuda_rasterizer/forward.cu:184-231) and the
+// seed <= 0 branch of the tet one (cuda_renderer/forward.cu:90-145).  Recomputed inside the
+// compositing kernels instead of being stored (saves 24 B/pixel each way).
+template <bool TET>
+__device__ __forceinline__ void pixel_ray(const float* __restrict__ inv_mv, const float* __restrict__ inv_proj,
+                                          int px, int py, int W, int H, V3& o, V3& d) {
+    o = {inv_mv[12], inv_mv[13], inv_mv[14]};
+    V2 pixf = {px + 0.5f, py + 0.5f};
+    V2 nd = {pix2ndc(pixf.x, W), pix2ndc(pixf.y, H)};
+    V4 pv = xform4x4({nd.x, nd.y, -1.0f}, inv_proj);
+    V4 pw = xform4x4({pv.x, pv.y, pv.z}, inv_mv);
+    d = V3{pw.x, pw.y, pw.z} - o;
+    float len;
+    if (TET) { len = sqrtf(dot(d, d)); len = fmaxf(len, 0.0001f); }
+    else len = sqrtf(dot(d, d)) + 0.0000001f;
+    d = d / len;
+}
+
+// auxiliary.h:335-372
+__device__ __forceinline__ void clamp_bary_uv(float u, float v, float& u_c, float& v_c, int& code) {
+    if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) { u_c = u; v_c = v; code = 0; }
+    else if (u <= 0.0f && v <= 0.0f) { u_c = 0.0f; v_c = 0.0f; code = 1; }
+    else if ((u >= 1.0f && v <= 0.0f) || (v >= 0.0f && v <= u - 1.0f)) { u_c = 1.0f; v_c = 0.0f; code = 2; }
+    else if ((u <= 0.0f && v >= 1.0f) || (u >= 0.0f && v >= u + 1.0f)) { u_c = 0.0f; v_c = 1.0f; code = 3; }
+    else if (u <= 0.0f && v <= 1.0f && v >= 0.0f) { u_c = 0.0f; v_c = v; code = 4; }
+    else if (u <= 1.0f && u >= 0.0f && v <= 0.0f) { u_c = u; v_c = 0.0f; code = 5; }
+    else { u_c = (1.0f + u - v) * 0.5f; v_c = (1.0f - u + v) * 0.5f; code = 6; }
+}
+
+// auxiliary.h:374-400
+__device__ __forceinline__ void clamp_bary_uv_grad(int code, float& duc_du, float& duc_dv, float& dvc_du, float& dvc_dv) {
+    dvc_du = 0.0f; duc_dv = 0.0f;
+    if (code == 0) { duc_du = 1.0f; dvc_dv = 1.0f; }
+    else if (code == 1 || code == 2 || code == 3) { duc_du = 0.0f; dvc_dv = 0.0f; }
+    else if (code == 4) { duc_du = 0.0f; dvc_dv = 1.0f; }
+    else if (code == 5) { duc_du = 1.0f; dvc_dv = 0.0f; }
+    else { duc_du = 0.5f; dvc_du = -0.5f; duc_dv = -0.5f; dvc_dv = 0.5f; }
+}
+
+// Moeller-Trumbore, tet flavour with the real hit test (cuda_renderer/auxiliary.h:265-296)
+__device__ __forceinline__ bool ray_tri_hit(V3 o, V3 d, V3 p0, V3 p1, V3 p2, V3& tuv) {
+    V3 T = o - p0, E1 = p1 - p0, E2 = p2 - p0;
+    V3 P = cross(d, E2), Q = cross(T, E1);
+    float denom = dot(P, E1);
+    if (denom == 0.0f) return false;
+    float inv_denom = 1.0f / denom;
+    tuv.x = dot(Q, E2) * inv_denom;
+    tuv.y = dot(P, T) * inv_denom;
+    tuv.z = dot(Q, d) * inv_denom;
+    return (tuv.x >= 0.0f && tuv.y >= 0.0f && tuv.z >= 0.0f && tuv.y + tuv.z <= 1.0f);
+}
+
+__device__ __forceinline__ V3 load_v3(const float* __restrict__ a, int id) {
+    return {a[3 * id], a[3 * id + 1], a[3 * id + 2]};
+}
+
+// cuda_renderer/auxiliary.h:345-394
+__device__ __forceinline__ V3 tet_face_outward_normal(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                      const int* __restrict__ tets, int face_idx, int tet_idx) {
+    V3 p0 = load_v3(verts, faces[3 * face_idx]);
+    V3 p1 = load_v3(verts, faces[3 * face_idx + 1]);
+    V3 p2 = load_v3(verts, faces[3 * face_idx + 2]);
+    V3 n = cross(p1 - p0, p2 - p0);
+    float n_norm = sqrtf(dot(n, n));
+    n_norm = fmaxf(n_norm, 0.0001f);
+    n = n / n_norm;
+    V3 q0 = load_v3(verts, tets[4 * tet_idx]), q1 = load_v3(verts, tets[4 * tet_idx + 1]);
+    V3 q2 = load_v3(verts, tets[4 * tet_idx + 2]), q3 = load_v3(verts, tets[4 * tet_idx + 3]);
+    V3 center = (q0 + q1 + q2 + q3) * 0.25f;
+    if (dot(n, center - p0) > 0.0f) n = -n;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// Coverage set-up: the reference's in_tri (auxiliary.h:179-243) evaluates three 28.4
+// fixed-point edge functions per (pixel, face).  Everything that does not depend on the
+// pixel is hoisted here, once per staged face: with px = 16*x + 8, py = 16*y + 8 (the
+// pixel centre (x + 0.5) * 16, exact in fp32) each edge function is
+//     s_i(x, y) = s0_i + bx_i * (x - x0) + by_i * (y - y0)      (mod 2^32, as int32 wraps, Q7)
+// for a tile whose first pixel is (x0, y0).  `ok` is false for zero-area faces.
+// ---------------------------------------------------------------------------
+struct EdgeSetup { int32_t s0[3], bx[3], by[3]; bool ok; };
+
+__device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int y0) {
+    const float sub = 16.0f;
+    uint32_t x1 = (uint32_t)f2i(p1.x * sub), y1 = (uint32_t)f2i(p1.y * sub);
+    uint32_t x2 = (uint32_t)f2i(p2.x * sub), y2 = (uint32_t)f2i(p2.y * sub);
+    uint32_t x3 = (uint32_t)f2i(p3.x * sub), y3 = (uint32_t)f2i(p3.y * sub);
+    int32_t area = (int32_t)((x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1));
+    EdgeSetup e;
+    e.ok = (area != 0);
+    if (area < 0) { uint32_t t = x2; x2 = x3; x3 = t; t = y2; y2 = y3; y3 = t; }
+    const uint32_t cx[3] = {x1 - x2, x2 - x3, x3 - x1};
+    const uint32_t cy[3] = {y1 - y2, y2 - y3, y3 - y1};
+    const uint32_t vx[3] = {x1, x2, x3};
+    const uint32_t vy[3] = {y1, y2, y3};
+    const uint32_t px = (uint32_t)(16 * x0 + 8), py = (uint32_t)(16 * y0 + 8);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint32_t s = cx[i] * (py - vy[i]) - cy[i] * (px - vx[i]);
+        if ((int32_t)cy[i] > 0 || ((int32_t)cy[i] == 0 && (int32_t)cx[i] > 0)) s -= 1u;  // top-left rule
+        e.s0[i] = (int32_t)s;
+        e.bx[i] = (int32_t)(0u - 16u * cy[i]);
+        e.by[i] = (int32_t)(16u * cx[i]);
+    }
+    return e;
+}
+
+__device__ __forceinline__ bool edge_inside(const int32_t* s0, const int32_t* bx, const int32_t* by, int lx, int ly) {
+    uint32_t s1 = (uint32_t)s0[0] + (uint32_t)bx[0] * (uint32_t)lx + (uint32_t)by[0] * (uint32_t)ly;
+    uint32_t s2 = (uint32_t)s0[1] + (uint32_t)bx[1] * (uint32_t)lx + (uint32_t)by[1] * (uint32_t)ly;
+    uint32_t s3 = (uint32_t)s0[2] + (uint32_t)bx[2] * (uint32_t)lx + (uint32_t)by[2] * (uint32_t)ly;
+    return (int32_t)(s1 & s2 & s3) < 0;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+}  // namespace dmr

@@ -1,0 +1,58 @@
+// dmr_kernels.hpp -- internal launcher declarations (host side of the gfx950 kernels).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dmesh_renderer_amd.h"
+#include "dmr_device.hpp"
+
+namespace dmr {
+
+// Packed gradient accumulators of the backward passes (DMR_BUF_WORK):
+//   vertex row  [B][P][8] = { dx, dy, dz, dr, dg, db, ddepth, - }   one 32-byte row per (view, vertex)
+//   face row    [B][F][2] = { dopacity, dintense }
+// so that one (tile, face) flush touches 3 vertex rows + 1 face row (4 memory-side atomic
+// requests) instead of 23 scattered dwords.
+constexpr int VROW = 8;
+constexpr int FROW = 2;
+
+// ---- binning (dmr_binning.hip)
+void launch_project_verts(const dmr_scene& s, float4* vproj, hipStream_t st);
+void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int gx, int gy, int r0, int r1,
+                        uint2* face_rect, float* key_depth, float* max_depth, uint32_t* tiles_touched,
+                        uint32_t* tile_count, hipStream_t st);
+void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
+                       int* num_rendered, hipStream_t st);
+void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
+                          const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
+                          hipStream_t st);
+void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, hipStream_t st);
+
+// ---- tri compositing (dmr_tri.hip)
+struct TriImageState { float* final_T; float* final_prev_T; uint32_t* n_contrib; };
+void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
+                        const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
+                        float* out_color, float* out_depth, hipStream_t st);
+void launch_tri_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
+                         const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
+                         const float* dL_dcolor, const float* dL_ddepth, float* vrow, float* frow, hipStream_t st);
+void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
+                       float* dL_dvcolor, float* dL_dfopacity, float* dL_dvdepth, float* dL_dfintense,
+                       hipStream_t st);
+
+// ---- tet ray march (dmr_tet.hip)
+struct TetImageState {
+    float* final_log_T; float* final_prev_log_T; uint32_t* n_contrib;
+    int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
+};
+void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
+                                const float* max_depth, const uint32_t* tile_offset, const uint32_t* face_list,
+                                TetImageState img, hipStream_t st);
+void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
+                        float* out_color, float* out_depth, float* out_active, hipStream_t st);
+void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
+                         const float* dL_dcolor, const float* dL_ddepth, float* dL_dvcolor, float* dL_dfopacity,
+                         hipStream_t st);
+
+}  // namespace dmr

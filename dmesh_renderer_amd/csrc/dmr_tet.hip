@@ -1,0 +1,340 @@
+// dmr_tet.hip -- tet renderer: first hit per pixel, then tet-to-tet ray march (gfx950).
+//
+// Replaces firstIntersectCUDA (cuda_renderer/forward.cu:298-445), TET_FORWARD::renderCUDA
+// (cuda_renderer/forward.cu:485-815) and TET_BACKWARD::renderCUDA (cuda_renderer/backward.cu:86-487).
+//
+// first_intersect walks the tile's min-depth-sorted face list in LDS-staged chunks (one
+// 16x16 tile per 256-thread workgroup, wave w = 8x8 quadrant w); the march kernels are one
+// thread per pixel with dependent gathers through tet_faces -> faces -> verts.
+// Rays are recomputed per pixel (seed <= 0 branch of generateRaysCUDA, forward.cu:124-127).
+// Guards: Q17 (no work when P/F/T == 0), Q18 (only pixels inside the image are touched),
+// Q19 (the unread is_active_backward diagnostic is dropped).
+#include "dmr_kernels.hpp"
+
+namespace dmr {
+
+constexpr int FI_CHUNK = 256;
+
+struct alignas(16) HitRec { float p0[3], p1[3], p2[3]; float min_depth, max_depth; int face; };
+static_assert(sizeof(HitRec) == 48, "HitRec");
+
+struct TetParams {
+    int B, P, F, W, H, gx, gy, r0;
+    const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
+    const float* mv; const float* proj; const float* inv_mv; const float* inv_proj;
+    const float* faces_intense; const float* bg;
+    const int* tets; const int* face_tets; const int* tet_faces;
+    TetImageState img;
+};
+
+__global__ void __launch_bounds__(256)
+k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const float* __restrict__ max_depth,
+                      const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ face_list) {
+    __shared__ HitRec s_rec[FI_CHUNK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
+    const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
+    const int px = tx * TILE + lx, py = ty * TILE + ly;
+    const bool inside = px < p.W && py < p.H;
+    const int64_t bpix = (int64_t)b * p.H * p.W + (int64_t)p.W * py + px;
+
+    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    if (inside) pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
+
+    const int tile = (b * p.gy + ty) * p.gx + tx;
+    const uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
+
+    bool done = !inside;
+    float min_T = -1.0f, min_T_max_depth = -1.0f;
+    int ff = -1;
+    for (uint32_t base = begin; base < end; base += FI_CHUNK) {
+        if (__syncthreads_and(done)) break;
+        const int n = (int)min((uint32_t)FI_CHUNK, end - base);
+        if (tid < n) {
+            const int face = (int)face_list[base + tid];
+            const V3 a = load_v3(p.verts, p.faces[3 * face]);
+            const V3 c = load_v3(p.verts, p.faces[3 * face + 1]);
+            const V3 e = load_v3(p.verts, p.faces[3 * face + 2]);
+            HitRec& r = s_rec[tid];
+            r.p0[0] = a.x; r.p0[1] = a.y; r.p0[2] = a.z;
+            r.p1[0] = c.x; r.p1[1] = c.y; r.p1[2] = c.z;
+            r.p2[0] = e.x; r.p2[1] = e.y; r.p2[2] = e.z;
+            r.min_depth = key_depth[(int64_t)b * p.F + face];
+            r.max_depth = max_depth[(int64_t)b * p.F + face];
+            r.face = face;
+        }
+        __syncthreads();
+        for (int j = 0; !done && j < n; j++) {
+            const HitRec& r = s_rec[j];
+            if (min_T >= 0.0f && r.min_depth > min_T_max_depth) { done = true; continue; }
+            V3 tuv;
+            if (!ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
+                             {r.p2[0], r.p2[1], r.p2[2]}, tuv))
+                continue;
+            if (min_T < 0.0f || tuv.x < min_T) { min_T = tuv.x; min_T_max_depth = r.max_depth; ff = r.face; }
+        }
+    }
+    if (!inside) return;
+    int ft = -1;
+    if (ff >= 0) {
+        for (int i = 0; i < 2; i++) {
+            const int tet_id = p.face_tets[2 * ff + i];
+            if (tet_id < 0) continue;
+            const V3 n = tet_face_outward_normal(p.verts, p.faces, p.tets, ff, tet_id);
+            if (dot(n, rd) < 0.0f) ft = tet_id;
+        }
+    }
+    p.img.first_face[bpix] = ff;
+    p.img.first_tet[bpix] = ft;
+}
+
+__device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int face, float& rt, float& iu, float& iv) {
+    V3 tuv = {0, 0, 0};
+    ray_tri_hit(ro, rd, load_v3(p.verts, p.faces[3 * face]), load_v3(p.verts, p.faces[3 * face + 1]),
+                load_v3(p.verts, p.faces[3 * face + 2]), tuv);
+    rt = tuv.x; iu = tuv.y; iv = tuv.z;
+}
+
+// One march step shared by forward (FWD: leave through the face whose outward normal follows
+// the ray) and backward (enter face: normal against the ray).  Returns false when the march
+// must stop ("error cases" 1-3 of the reference).
+template <bool FWD>
+__device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet,
+                                           float& curr_rt, float& curr_iu, float& curr_iv) {
+    int others[3];
+    int cnt = 0;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int tf = p.tet_faces[4 * curr_tet + i];
+        if (tf == curr_face) continue;
+        if (cnt < 3) others[cnt] = tf;
+        cnt++;
+    }
+    if (cnt != 3) return false;
+    const V3 ncur = tet_face_outward_normal(p.verts, p.faces, p.tets, curr_face, curr_tet);
+    const float dcur = dot(ncur, rd);
+    if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
+    int nf = -1, ncnt = 0;
+    float nrt = 0, niu = 0, niv = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        V3 tuv;
+        const int of = others[i];
+        const bool hit = ray_tri_hit(ro, rd, load_v3(p.verts, p.faces[3 * of]), load_v3(p.verts, p.faces[3 * of + 1]),
+                                     load_v3(p.verts, p.faces[3 * of + 2]), tuv);
+        const V3 n = tet_face_outward_normal(p.verts, p.faces, p.tets, of, curr_tet);
+        const float dn = dot(n, rd);
+        if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) { nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; ncnt++; }
+    }
+    if (ncnt != 1 || !ok) return false;
+    int nt = -1;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int t = p.face_tets[2 * nf + i];
+        if (t == curr_tet || t == -1) continue;
+        nt = t;
+        break;
+    }
+    curr_face = nf; curr_tet = nt; curr_rt = nrt; curr_iu = niu; curr_iv = niv;
+    return true;
+}
+
+__global__ void __launch_bounds__(256)
+k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_active) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= p.W || py >= p.H) return;
+    const int64_t HW = (int64_t)p.H * p.W, pix_id = (int64_t)p.W * py + px, bpix = (int64_t)b * HW + pix_id;
+    V3 ro, rd;
+    pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
+    const float* mv = p.mv + 16 * b;
+    const float* pr = p.proj + 16 * b;
+    const int first_face = p.img.first_face[bpix], first_tet = p.img.first_tet[bpix];
+
+    bool done = false;
+    int curr_face = first_face, curr_tet = first_tet;
+    float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
+    if (first_face == -1 || first_tet == -1) done = true;
+    else face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv);
+
+    V3 C = {0, 0, 0};
+    float D = 0.f, log_T = 0.f, prev_log_T = 0.f;
+    int last_face = -1, last_tet = -1;
+    bool active = false;
+    uint32_t n_contrib = 0;
+    while (!done) {
+        const V3 c0 = load_v3(p.verts_color, p.faces[3 * curr_face]);
+        const V3 c1 = load_v3(p.verts_color, p.faces[3 * curr_face + 1]);
+        const V3 c2 = load_v3(p.verts_color, p.faces[3 * curr_face + 2]);
+        V3 col = (c0 + (c1 - c0) * curr_iu + (c2 - c0) * curr_iv);  // Q21
+        const float opacity = p.faces_opacity[curr_face];
+        const float intense = p.faces_intense[(int64_t)b * p.F + curr_face];
+        col = col * intense;
+        const float tmp_T = expf(log_T);
+        C = C + tmp_T * opacity * col;
+        const V3 pt = ro + (rd * curr_rt);
+        const V4 pn = xform4x4(xform4x3(pt, mv), pr);
+        const float pw = 1.0f / clamp_w(pn.w);
+        D += tmp_T * opacity * (pn.z * pw);
+        prev_log_T = log_T;
+        if (opacity < 1.0f) log_T += logf(1.0f - opacity);
+        else log_T = logf(T_EPS * 0.1f);
+        if (expf(log_T) < T_EPS) { done = true; active = true; }
+        n_contrib++;
+        last_face = curr_face;
+        last_tet = curr_tet;
+        if (curr_tet == -1) { active = true; done = true; }
+        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv)) done = true;
+    }
+    p.img.final_log_T[bpix] = log_T;
+    p.img.final_prev_log_T[bpix] = prev_log_T;
+    p.img.last_face[bpix] = last_face;
+    p.img.last_tet[bpix] = last_tet;
+    p.img.n_contrib[bpix] = n_contrib;
+    p.img.is_active[bpix] = active ? 1 : 0;
+    if (active) {
+        const float fT = expf(log_T);
+        out_color[((int64_t)b * 3 + 0) * HW + pix_id] = C.x + fT * p.bg[0];
+        out_color[((int64_t)b * 3 + 1) * HW + pix_id] = C.y + fT * p.bg[1];
+        out_color[((int64_t)b * 3 + 2) * HW + pix_id] = C.z + fT * p.bg[2];
+        out_depth[bpix] = D + fT * 1.0f;
+        out_active[bpix] = 1.0f;
+    } else {
+        out_color[((int64_t)b * 3 + 0) * HW + pix_id] = p.bg[0];
+        out_color[((int64_t)b * 3 + 1) * HW + pix_id] = p.bg[1];
+        out_color[((int64_t)b * 3 + 2) * HW + pix_id] = p.bg[2];
+        out_depth[bpix] = 1.0f;
+        out_active[bpix] = 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+               float* __restrict__ dL_dvcolor, float* __restrict__ dL_dfopacity) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= p.W || py >= p.H) return;
+    const int64_t HW = (int64_t)p.H * p.W, pix_id = (int64_t)p.W * py + px, bpix = (int64_t)b * HW + pix_id;
+    if (!p.img.is_active[bpix]) return;
+    const int last_face = p.img.last_face[bpix];
+    if (last_face == -1) return;
+    const int first_face = p.img.first_face[bpix];
+    const float fprev = p.img.final_prev_log_T[bpix], flog = p.img.final_log_T[bpix];
+    const float final_prev_T = expf(fprev), final_T = expf(flog);
+    float prev_log_T = fprev;
+    const float dpc0 = dL_dcolor[((int64_t)b * 3 + 0) * HW + pix_id];
+    const float dpc1 = dL_dcolor[((int64_t)b * 3 + 1) * HW + pix_id];
+    const float dpc2 = dL_dcolor[((int64_t)b * 3 + 2) * HW + pix_id];
+    const float dpd = dL_ddepth[bpix];
+    float bg_dot = 0.f;
+    bg_dot += p.bg[0] * dpc0; bg_dot += p.bg[1] * dpc1; bg_dot += p.bg[2] * dpc2;
+    const float bd_dot = 0.f + (float)(1.0 * (double)dpd);
+
+    V3 ro, rd;
+    pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
+    const float* mv = p.mv + 16 * b;
+    const float* pr = p.proj + 16 * b;
+
+    int curr_face = last_face, curr_tet = p.img.last_tet[bpix];
+    float curr_rt, curr_iu, curr_iv;
+    face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv);
+    // step back across the last face (backward.cu:223-232)
+    for (int i = 0; i < 2; i++) {
+        const int t = p.face_tets[2 * curr_face + i];
+        if (t == curr_tet) continue;
+        curr_tet = t;
+        break;
+    }
+    float last_alpha = 0.f, lc0 = 0, lc1 = 0, lc2 = 0, ar0 = 0, ar1 = 0, ar2 = 0, last_depth = 0.f, ard = 0.f;
+    bool first_iter = true, done = false;
+    while (!done) {
+        const int v0 = p.faces[3 * curr_face], v1 = p.faces[3 * curr_face + 1], v2 = p.faces[3 * curr_face + 2];
+        const V3 c0 = load_v3(p.verts_color, v0), c1 = load_v3(p.verts_color, v1), c2 = load_v3(p.verts_color, v2);
+        const float i0 = 1.0f - curr_iu - curr_iv, i1 = curr_iu, i2 = curr_iv;
+        V3 col = (i0 * c0) + (i1 * c1) + (i2 * c2);  // Q21
+        const float opacity = p.faces_opacity[curr_face];
+        const float intense = p.faces_intense[(int64_t)b * p.F + curr_face];
+        col = col * intense;
+        const V3 pt = ro + (rd * curr_rt);
+        const V4 pn = xform4x4(xform4x3(pt, mv), pr);
+        const float pw = 1.0f / clamp_w(pn.w);
+        const float pdepth = pn.z * pw;
+        if (!first_iter) prev_log_T = prev_log_T - logf(1.0f - opacity);
+        first_iter = false;
+        const float prev_T = expf(prev_log_T);
+
+        float dop = 0.f;
+        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = col.x;
+        const float dc0 = dpc0 * opacity * prev_T; dop += (col.x - ar0) * dpc0;
+        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = col.y;
+        const float dc1 = dpc1 * opacity * prev_T; dop += (col.y - ar1) * dpc1;
+        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = col.z;
+        const float dc2 = dpc2 * opacity * prev_T; dop += (col.z - ar2) * dpc2;
+        ard = last_alpha * last_depth + (1.f - last_alpha) * ard; last_depth = pdepth;
+        dop += (pdepth - ard) * dpd;
+        dop *= prev_T;
+        last_alpha = opacity;
+        if (opacity == 1.0f) {
+            dop += (-final_prev_T) * bg_dot;
+            dop += (-final_prev_T) * bd_dot;
+        } else {
+            dop += (-final_T / (1.f - opacity)) * bg_dot;
+            dop += (-final_T / (1.f - opacity)) * bd_dot;
+        }
+        atomicAdd(&dL_dvcolor[3 * v0 + 0], i0 * dc0 * intense);
+        atomicAdd(&dL_dvcolor[3 * v0 + 1], i0 * dc1 * intense);
+        atomicAdd(&dL_dvcolor[3 * v0 + 2], i0 * dc2 * intense);
+        atomicAdd(&dL_dvcolor[3 * v1 + 0], i1 * dc0 * intense);
+        atomicAdd(&dL_dvcolor[3 * v1 + 1], i1 * dc1 * intense);
+        atomicAdd(&dL_dvcolor[3 * v1 + 2], i1 * dc2 * intense);
+        atomicAdd(&dL_dvcolor[3 * v2 + 0], i2 * dc0 * intense);
+        atomicAdd(&dL_dvcolor[3 * v2 + 1], i2 * dc1 * intense);
+        atomicAdd(&dL_dvcolor[3 * v2 + 2], i2 * dc2 * intense);
+        atomicAdd(&dL_dfopacity[curr_face], dop);
+
+        if (curr_face == first_face) done = true;
+        if (!done) {
+            if (curr_tet == -1) done = true;
+            else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv)) done = true;
+        }
+    }
+}
+
+static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImageState img) {
+    TetParams p;
+    p.B = s.B; p.P = s.P; p.F = s.F; p.W = s.W; p.H = s.H; p.gx = gx; p.gy = gy; p.r0 = r0;
+    p.verts = s.verts; p.faces = s.faces; p.verts_color = s.verts_color; p.faces_opacity = s.faces_opacity;
+    p.mv = s.mv_mats; p.proj = s.proj_mats; p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats;
+    p.faces_intense = s.faces_intense; p.bg = s.background;
+    p.tets = s.tets; p.face_tets = s.face_tets; p.tet_faces = s.tet_faces;
+    p.img = img;
+    return p;
+}
+
+void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
+                                const float* max_depth, const uint32_t* tile_offset, const uint32_t* face_list,
+                                TetImageState img, hipStream_t st) {
+    if (r1 <= r0) return;
+    TetParams p = make_params(s, gx, gy, r0, img);
+    k_tet_first_intersect<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, key_depth, max_depth, tile_offset, face_list);
+}
+
+void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
+                        float* out_color, float* out_depth, float* out_active, hipStream_t st) {
+    if (r1 <= r0) return;
+    TetParams p = make_params(s, gx, gy, r0, img);
+    k_tet_forward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, out_color, out_depth, out_active);
+}
+
+void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
+                         const float* dL_dcolor, const float* dL_ddepth, float* dL_dvcolor, float* dL_dfopacity,
+                         hipStream_t st) {
+    if (r1 <= r0) return;
+    TetParams p = make_params(s, gx, gy, r0, img);
+    k_tet_backward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity);
+}
+
+}  // namespace dmr

@@ -1,0 +1,114 @@
+/*
+ * dmesh_renderer_amd.h -- C ABI of libdmesh_renderer_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the hot path of SonSang/dmesh_renderer: the four
+ * entry points below replace what the reference's pybind module `_C` (ext.cpp:6-11)
+ * reaches through render.cu:
+ *
+ *   dmr_tri_forward   <- CudaRasterizer::Rasterizer::forward  (cuda_rasterizer/rasterizer.h:13-42,
+ *                        called from RasterizeTrianglesCUDA, render.cu:107-129)
+ *   dmr_tri_backward  <- CudaRasterizer::Rasterizer::backward (rasterizer.h:44-67, render.cu:175-204)
+ *   dmr_tet_forward   <- CudaRenderer::Renderer::forward      (cuda_renderer/renderer.h:12-46, render.cu:303-334)
+ *   dmr_tet_backward  <- CudaRenderer::Renderer::backward     (renderer.h:48-75, render.cu:378-409)
+ *
+ * Plain pointers and sizes only: every pointer is a DEVICE pointer unless stated,
+ * tensors are dense row-major fp32 / int32 exactly as render.cu hands them down
+ * (`.contiguous().data<T>()`), matrices are [B,16] column-major m[4*col+row]
+ * (auxiliary.h:71-90).  `stream` is a hipStream_t (NULL = default stream).  All work
+ * is enqueued on that stream; the only host synchronisation is the 4-byte read of
+ * num_rendered in the forward calls (reference: rasterizer_impl.cu:287-292).
+ *
+ * Return value: 0 on success, non-zero on error; dmr_last_error() then returns a
+ * message for the calling thread (the glue raises RuntimeError with it, as the
+ * reference's CHECK_CUDA -> std::runtime_error does, auxiliary.h:425-432).
+ */
+#ifndef DMESH_RENDERER_AMD_H
+#define DMESH_RENDERER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMR_ABI_VERSION 1
+
+/* Scratch buffers.  The first four are the reference's pointBuffer / faceBuffer /
+ * binningBuffer / imageBuffer (rasterizer.h:14-17): opaque byte buffers that the
+ * caller owns, returns from forward and passes back to backward.  DMR_BUF_WORK is a
+ * transient workspace of the backward calls (packed gradient accumulators). */
+enum { DMR_BUF_POINT = 0, DMR_BUF_FACE = 1, DMR_BUF_BINNING = 2, DMR_BUF_IMAGE = 3, DMR_BUF_WORK = 4 };
+
+/* C equivalent of the reference's four std::function<char*(size_t)> allocators
+ * (rasterizer.h:14-17, render.cu:18-24): must return a device pointer to at least
+ * `nbytes` bytes (256-byte aligned), or NULL on failure.  Called at most once per
+ * buffer per call, from the calling thread. */
+typedef void* (*dmr_alloc_fn)(void* ctx, int which, size_t nbytes);
+
+typedef struct dmr_scene {
+    int32_t B, P, F, T, W, H;    /* views, verts, faces, tets (0 for tri), image size */
+    const float* background;     /* [3] */
+    const float* verts;          /* [P,3] */
+    const int32_t* faces;        /* [F,3] */
+    const float* verts_color;    /* [P,3] */
+    const float* faces_opacity;  /* [F] */
+    const float* mv_mats;        /* [B,16] column-major */
+    const float* proj_mats;      /* [B,16] */
+    const float* inv_mv_mats;    /* [B,16] */
+    const float* inv_proj_mats;  /* [B,16] */
+    const float* verts_depth;    /* [B,P] */
+    const float* faces_intense;  /* [B,F] */
+    const int32_t* tets;         /* [T,4]  tet renderer only */
+    const int32_t* face_tets;    /* [F,2]  tet renderer only, -1 = no tet */
+    const int32_t* tet_faces;    /* [T,4]  tet renderer only */
+    int32_t ray_random_seed;     /* tet renderer only; <= 0: rays through pixel centres */
+    /* Tile-row band [row_begin, row_end) this call renders (multi-GPU shard by tile
+     * rows); 0,0 means all rows.  Pixels outside the band are left untouched. */
+    int32_t row_begin, row_end;
+} dmr_scene;
+
+/* out_color [B,3,H,W], out_depth [B,1,H,W] must be zero-initialised by the caller
+ * (render.cu:88-89).  *num_rendered receives R = sum of tiles touched. */
+int dmr_tri_forward(const dmr_scene* scene, float* out_color, float* out_depth,
+                    dmr_alloc_fn alloc, void* alloc_ctx, void* stream, int* num_rendered);
+
+/* Gradient outputs are fully overwritten: dL_dverts [P,3], dL_dvcolor [P,3],
+ * dL_dfopacity [F], dL_dvdepth [B,P], dL_dfintense [B,F]. */
+int dmr_tri_backward(const dmr_scene* scene, const float* dL_dcolor, const float* dL_ddepth,
+                     int num_rendered, const void* point_buf, const void* face_buf,
+                     const void* binning_buf, const void* image_buf,
+                     float* dL_dverts, float* dL_dvcolor, float* dL_dfopacity,
+                     float* dL_dvdepth, float* dL_dfintense,
+                     dmr_alloc_fn alloc, void* alloc_ctx, void* stream);
+
+/* out_active [B,H,W]: 1.0 where the ray marched to a valid end, else 0.0. */
+int dmr_tet_forward(const dmr_scene* scene, float* out_color, float* out_depth, float* out_active,
+                    dmr_alloc_fn alloc, void* alloc_ctx, void* stream, int* num_rendered);
+
+/* dL_dvcolor [P,3], dL_dfopacity [F], fully overwritten. */
+int dmr_tet_backward(const dmr_scene* scene, const float* dL_dcolor, const float* dL_ddepth,
+                     const void* point_buf, const void* face_buf,
+                     const void* binning_buf, const void* image_buf,
+                     float* dL_dvcolor, float* dL_dfopacity,
+                     dmr_alloc_fn alloc, void* alloc_ctx, void* stream);
+
+/* Parity/debug export of forward intermediates held in the scratch buffers.
+ * name: "image" (f32 [B*P,2]) "ndc_z" (f32 [B*P]) "key_depth" (f32 [B*F]) "max_depth" (tet, f32 [B*F])
+ * "tiles_touched" (u32 [B*F]) "ranges" (u32 [B*Nt,2]) "face_list" (u32 [R]) "final_T" "final_prev_T"
+ * (f32 [B*W*H]) "n_contrib" (u32 [B*W*H]) "first_face" "first_tet" "last_face" "last_tet" (i32, tet)
+ * "is_active" (u8, tet).  dst is a DEVICE pointer with room for `cap` bytes.  Returns the byte size
+ * of the item (copying min(size, cap) when dst != NULL), or -1. */
+int64_t dmr_export(const dmr_scene* scene, int is_tet, int num_rendered, const char* name,
+                   const void* point_buf, const void* face_buf, const void* binning_buf,
+                   const void* image_buf, void* dst, int64_t cap, void* stream);
+
+const char* dmr_last_error(void);
+int dmr_abi_version(void);
+/* Name of the code object architecture the library was built for ("gfx950"). */
+const char* dmr_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMESH_RENDERER_AMD_H */

@@ -1,0 +1,162 @@
+"""tri renderer: HIP path (through `_C` -> C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): tile/sort indices bit-exact; forward pixels <= 1e-5;
+gradients <= 1e-4 (max-abs error relative to max(1, max-abs of the oracle gradient)).
+"""
+import numpy as np
+import pytest
+import torch as th
+
+from dmesh_renderer_amd import scenes
+from util import c_args, rel_err, upstream_grads
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+GRAD_TOL = 1e-4
+
+CASES = {
+    # name: (layers, n, B, H, W, opacity)
+    "C1": (4, 17, 1, 256, 256, (0.1, 0.5)),                 # BASELINE configs[0]
+    "C1_opaque": (4, 17, 1, 256, 256, (0.5, 0.95)),         # exercises early termination (T < 1e-4)
+    "ragged": (3, 12, 2, 200, 328, (0.1, 0.6)),             # W, H not multiples of 16; two views
+    "dense": (12, 9, 1, 64, 64, (0.05, 0.3)),               # long tile lists: several LDS chunks per tile
+}
+
+
+def _run(oracle, dev, d, H, W, rows=(0, 0)):
+    from dmesh_renderer_amd import _C
+    sc = oracle.scene_from_module_inputs(d, H, W, rows=rows)
+    ocolor, odepth, ost = oracle.tri_forward(sc)
+    args = c_args(d, dev)
+    out = _C.render_tris(*args, H, W, rows=rows)
+    th.cuda.synchronize()
+    return sc, (ocolor, odepth, ost), args, out
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_forward_and_indices(oracle, hip_device, case):
+    from dmesh_renderer_amd import _C
+    L, n, B, H, W, op = CASES[case]
+    d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
+    sc, (ocolor, odepth, ost), args, out = _run(oracle, hip_device, d, H, W)
+    R, color, depth, bufs = out[0], out[1], out[2], out[3:7]
+    assert R == ost.num_rendered
+
+    def ex(name, dtype):
+        return _C.export(name, args, False, R, bufs, H, W, dtype).cpu().numpy()
+
+    # bit-exact integer / index work
+    np.testing.assert_array_equal(ex("image", th.float32).view(np.uint32), ost.get("image").view(np.uint32))
+    np.testing.assert_array_equal(ex("ndc_z", th.float32).view(np.uint32),
+                                  ost.get("ndc").reshape(-1, 3)[:, 2].copy().view(np.uint32))
+    np.testing.assert_array_equal(ex("tiles_touched", th.int32).view(np.uint32), ost.get("tiles_touched"))
+    touched = ost.get("tiles_touched") > 0
+    np.testing.assert_array_equal(ex("key_depth", th.float32).view(np.uint32)[touched],
+                                  ost.get("depths").view(np.uint32)[touched])
+    np.testing.assert_array_equal(ex("ranges", th.int32).view(np.uint32), ost.get("ranges"))
+    np.testing.assert_array_equal(ex("face_list", th.int32).view(np.uint32), ost.get("values"))
+    np.testing.assert_array_equal(ex("n_contrib", th.int32).view(np.uint32), ost.get("n_contrib"))
+    # floating point outputs
+    assert np.abs(color.cpu().numpy() - ocolor).max() <= FWD_TOL
+    assert np.abs(depth.cpu().numpy() - odepth).max() <= FWD_TOL
+    assert np.abs(ex("final_T", th.float32) - ost.get("final_T")).max() <= FWD_TOL
+    if case == "C1_opaque":
+        assert (ost.get("final_T") < 1e-4).any(), "scene must exercise early termination"
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_backward(oracle, hip_device, case):
+    from dmesh_renderer_amd import _C
+    L, n, B, H, W, op = CASES[case]
+    d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
+    sc, (ocolor, odepth, ost), args, out = _run(oracle, hip_device, d, H, W)
+    gc, gd = upstream_grads(B, H, W)
+    og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+    g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7])
+    th.cuda.synchronize()
+    for got, key in zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")):
+        assert got.shape == og[key].shape
+        e = rel_err(got.cpu().numpy(), og[key])
+        assert e <= GRAD_TOL, f"{key}: {e}"
+
+
+def test_band_rows_compose(oracle, hip_device):
+    """Two tile-row bands rendered separately == the full render (forward pixels and summed grads)."""
+    from dmesh_renderer_amd import _C
+    L, n, B, H, W, op = CASES["ragged"]
+    d = scenes.layered_sheets(L, n, B, H, W, seed=3, opacity=op)
+    args = c_args(d, hip_device)
+    gc, gd = upstream_grads(B, H, W)
+    gc, gd = gc.to(hip_device), gd.to(hip_device)
+    full = _C.render_tris(*args, H, W)
+    gfull = _C.render_tris_backward(*args, gc, gd, full[0], *full[3:7])
+    gy = (H + 15) // 16
+    split = gy // 2
+    color = th.zeros_like(full[1]); depth = th.zeros_like(full[2])
+    gsum = [th.zeros_like(t) for t in gfull]
+    for rows in ((0, split), (split, gy)):
+        o = _C.render_tris(*args, H, W, rows=rows)
+        color += o[1]; depth += o[2]
+        gb = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7], rows=rows)
+        for a, b_ in zip(gsum, gb):
+            a += b_
+    assert th.equal(color, full[1]) and th.equal(depth, full[2])
+    for a, b_ in zip(gsum, gfull):
+        assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) <= GRAD_TOL
+
+
+def test_module_autograd(oracle, hip_device):
+    """TriRenderer Module: loss.backward() routes the five gradients like the reference wrapper."""
+    import dmesh_renderer_amd as dmr
+    L, n, B, H, W, op = CASES["C1"]
+    d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
+    dev = hip_device
+    t = {k: v.to(dev) for k, v in d.items()}
+    leaves = {k: t[k].clone().requires_grad_(True) for k in ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")}
+    r = dmr.TriRenderer(dmr.TriRenderSettings(H, W, t["bg"]))
+    color, depth = r(leaves["verts"], t["faces"].to(th.int64), leaves["verts_color"], leaves["faces_opacity"],
+                     t["mv_mats"], t["proj_mats"], leaves["verts_depth"], leaves["faces_intense"])
+    gc, gd = upstream_grads(B, H, W)
+    ((color * gc.to(dev)).sum() + (depth * gd.to(dev)).sum()).backward()
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    ocolor, odepth, ost = oracle.tri_forward(sc)
+    og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+    assert np.abs(color.detach().cpu().numpy() - ocolor).max() <= FWD_TOL
+    for k in leaves:
+        assert rel_err(leaves[k].grad.cpu().numpy(), og[k]) <= GRAD_TOL, k
+
+
+def test_empty_inputs(hip_device):
+    """P == 0 / F == 0: zeros and num_rendered == 0 without launching (render.cu:104-105,173; Q16)."""
+    from dmesh_renderer_amd import _C
+    dev = hip_device
+    d = scenes.layered_sheets(1, 3, 1, 32, 32)
+    for P, F in ((0, 0), (9, 0)):
+        dd = dict(d)
+        dd["verts"] = d["verts"][:P]; dd["verts_color"] = d["verts_color"][:P]; dd["verts_depth"] = d["verts_depth"][:, :P]
+        dd["faces"] = d["faces"][:F]; dd["faces_opacity"] = d["faces_opacity"][:F]; dd["faces_intense"] = d["faces_intense"][:, :F]
+        args = c_args(dd, dev)
+        out = _C.render_tris(*args, 32, 32)
+        assert out[0] == 0 and float(out[1].abs().max()) == 0.0 and float(out[2].abs().max()) == 0.0
+        g = _C.render_tris_backward(*args, th.ones(1, 3, 32, 32, device=dev), th.ones(1, 1, 32, 32, device=dev), out[0], *out[3:7])
+        assert [tuple(x.shape) for x in g] == [(P, 3), (P, 3), (F,), (1, P), (1, F)]
+        assert all(float(x.abs().sum()) == 0.0 for x in g)
+
+
+def test_shape_errors(hip_device):
+    from dmesh_renderer_amd import _C
+    d = scenes.layered_sheets(1, 3, 1, 32, 32)
+    args = c_args(d, hip_device)
+    bad = list(args); bad[1] = bad[1][:, :2]
+    with pytest.raises(RuntimeError, match="verts must have dimensions"):
+        _C.render_tris(*bad, 32, 32)
+    bad = list(args); bad[4] = bad[4][:-1]
+    with pytest.raises(RuntimeError, match="face opacity must have dimensions"):
+        _C.render_tris(*bad, 32, 32)
+    bad = list(args); bad[2] = bad[2].to(th.int64)
+    with pytest.raises(RuntimeError, match="expected scalar type Int"):
+        _C.render_tris(*bad, 32, 32)
+    cpu = c_args(d, None)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _C.render_tris(*cpu, 32, 32)
