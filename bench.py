@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+bwd Mpixels/s of the tri renderer at 1920x1080, 500k triangles (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one forward + one backward of the hot path (`_C.render_tris` + `_C.render_tris_backward`,
+i.e. the C ABI of libdmesh_renderer_hip.so) over one synthetic "layered sheets" scene (C4:
+16 sheets x 126^2 vertices = 500 000 triangles, one 1920x1080 view), inputs resident in HBM.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the image is sharded by
+work-balanced bands of tile rows, every rank renders and back-propagates its band, and the five
+gradient tensors are summed with ONE all-reduce over a flattened fp32 buffer (strong scaling).
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, HIP-event timed inside
+the timed region on the launch stream) and `cpu_baseline` (the CPU oracle = a port of the reference
+algorithm, timed on this box's host cores; N == 1 only).  The oracle is used only as checker/baseline.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch as th
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C4", help="scene config (C1, C2, C4, C5); the metric is quoted on C4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print a per-stage timing table to stderr")
+    return ap.parse_args()
+
+
+def balanced_bands(row_work: np.ndarray, n: int):
+    """Split tile rows into n contiguous bands of (nearly) equal work."""
+    w = row_work.astype(np.float64) + 1e-3  # empty rows still cost a launch
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for k in range(1, n):
+        cuts.append(int(np.searchsorted(cum, cum[-1] * k / n)))
+    cuts.append(len(row_work))
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[i], cuts[i + 1]) for i in range(n)]
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not th.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    th.cuda.set_device(local_rank)
+    dev = th.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    n_gpus = world
+
+    from dmesh_renderer_amd import _C, _lib, scenes
+    from dmesh_renderer_amd.scenes import c_args, rel_err, upstream_grads
+
+    cfg = scenes.CONFIGS[a.config]
+    d = scenes.make(a.config)
+    B, H, W = cfg.B, cfg.H, cfg.W
+    args = c_args(d, dev)
+    gc_cpu, gd_cpu = upstream_grads(B, H, W)
+    gc, gd = gc_cpu.to(dev), gd_cpu.to(dev)
+    P, F = d["verts"].shape[0], d["faces"].shape[0]
+    gy = (H + 15) // 16
+    gx = (W + 15) // 16
+
+    # tile-row band of this rank (work-balanced from one untimed full forward)
+    rows = (0, 0)
+    out = _C.render_tris(*args, H, W)
+    R_full = out[0]
+    if world > 1:
+        ranges = _C.export("ranges", args, False, out[0], out[3:7], H, W, th.int32).cpu().numpy().reshape(B, gy, gx, 2)
+        row_work = (ranges[..., 1] - ranges[..., 0]).sum(axis=(0, 2))
+        rows = balanced_bands(row_work, world)[rank]
+    del out
+
+    sizes = [3 * P, 3 * P, F, B * P, B * F]
+    flat = th.empty(sum(sizes), dtype=th.float32, device=dev)
+
+    def step():
+        o = _C.render_tris(*args, H, W, rows=rows)
+        g = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7], rows=rows)
+        if world > 1:
+            th.cat([t.reshape(-1) for t in g], out=flat)
+            dist.all_reduce(flat)  # ONE collective over the flattened gradient buffer
+        return o, g
+
+    lib = _lib.load()
+
+    def collect():
+        ms = (C.c_double * _lib.NUM_STAGES)()
+        cnt = (C.c_int64 * _lib.NUM_STAGES)()
+        lib.dmr_profile_collect(ms, cnt)
+        return np.array(ms[:]), np.array(cnt[:])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        th.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    # dominant kernels are HIP-event timed INSIDE the timed region (2 events per launch on the launch stream)
+    FWD, BWD = 5, 6
+    lib.dmr_profile_enable((1 << FWD) | (1 << BWD))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        o, g = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.dmr_profile_enable(0)
+    ms, cnt = collect()
+    R = o[0]
+    if world > 1:
+        tt = th.tensor([dt], dtype=th.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = B * W * H * a.steps / dt / 1e6
+
+    # roofline of the dominant kernel.  Algorithmic bytes (rays fused):
+    #   k_tri_forward  : 132 B per list entry (4 B id + 128 B face record) + 28 B per pixel
+    #   k_tri_backward : 132 B per list entry + 184 B per (tile, face) gradient RMW + 28 B per pixel
+    npix_band = B * W * min(H, (rows[1] - rows[0]) * 16) if world > 1 else B * W * H
+    alg = {FWD: 132.0 * R + 28.0 * npix_band, BWD: 316.0 * R + 28.0 * npix_band}
+    dom = FWD if ms[FWD] >= ms[BWD] else BWD
+    dom_ms = ms[dom] / max(1, cnt[dom])
+    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": lib.dmr_stage_name(dom).decode(), "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_ms": round(dom_ms, 4), "algorithmic_bytes": alg[dom],
+                "note": "composite kernels are VALU-bound (256 coverage tests per list entry), see DESIGN.md"}
+
+    # full per-stage table (separate, untimed-for-value pass)
+    lib.dmr_profile_enable(0xFFFFFFFF)
+    for _ in range(min(10, a.steps)):
+        step()
+    th.cuda.synchronize()
+    lib.dmr_profile_enable(0)
+    sms, scnt = collect()
+    stages = {lib.dmr_stage_name(i).decode(): round(float(sms[i] / scnt[i]), 4) for i in range(_lib.NUM_STAGES) if scnt[i]}
+    if a.stages and rank == 0:
+        print("per-stage avg ms:", json.dumps(stages), file=sys.stderr)
+
+    cpu_baseline = None
+    parity = {}
+    if world == 1 and not a.no_cpu_baseline and rank == 0:
+        from oracle import oracle as O  # checker / reported baseline only
+        O.build()
+        sc = O.scene_from_module_inputs(d, H, W)
+        t1 = time.perf_counter()
+        ocolor, odepth, ost = O.tri_forward(sc)
+        og = O.tri_backward(sc, ost, gc_cpu.numpy(), gd_cpu.numpy())
+        cdt = time.perf_counter() - t1
+        cores = int(O.lib().dmro_num_threads())
+        cpu_baseline = {"value": round(B * W * H / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                        "sample": f"1 fwd+bwd of the full {a.config} workload ({cdt:.1f} s, OpenMP {cores} threads)"}
+        parity["fwd_max_abs_err"] = float(max(np.abs(o[1].cpu().numpy() - ocolor).max(), np.abs(o[2].cpu().numpy() - odepth).max()))
+        parity["grad_max_abs_err"] = float(max(rel_err(t.cpu().numpy(), og[k]) for t, k in
+                                               zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense"))))
+        parity["num_rendered_equal"] = bool(R == ost.num_rendered)
+
+    if rank == 0:
+        line = {
+            "metric": "fwd+bwd Mpixels/sec @1080p, 500k tris; grad max-abs-err vs ref",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {cfg.name}, layered sheets seed 0, B={B}",
+                       "triangles": F, "verts": P, "image": [H, W], "num_rendered": int(R_full),
+                       "parallelism": "single GPU" if world == 1 else f"tile-row bands x{world} + 1 RCCL all-reduce"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stages,
+        }
+        line.update(parity)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "libdmesh_renderer_hip.so")
 ABI_VERSION = 1
 
 BUF_POINT, BUF_FACE, BUF_BINNING, BUF_IMAGE, BUF_WORK = range(5)
+NUM_STAGES = 11
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
@@ -44,6 +45,9 @@ EXPORTS = {
                          + [C.c_void_p] * 2 + [ALLOC_FN, C.c_void_p, C.c_void_p]),
     "dmr_export": (C.c_int64, [C.POINTER(Scene), C.c_int, C.c_int, C.c_char_p] + [C.c_void_p] * 4
                    + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "dmr_profile_enable": (None, [C.c_uint32]),
+    "dmr_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dmr_stage_name": (C.c_char_p, [C.c_int]),
     "dmr_last_error": (C.c_char_p, []),
     "dmr_abi_version": (C.c_int, []),
     "dmr_build_arch": (C.c_char_p, []),

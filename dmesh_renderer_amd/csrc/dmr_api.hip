@@ -7,9 +7,12 @@
 // enqueued on the caller's stream and the only host wait is that 4-byte read, which sizes the
 // binning buffer.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "dmr_kernels.hpp"
 
@@ -145,9 +148,71 @@ int run_binning(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     return 0;
 }
 
+// ---- per-stage timing ---------------------------------------------------------------------------
+std::atomic<uint32_t> g_prof_mask{0};
+struct ProfRec { int stage; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<ProfRec*> g_prof_live, g_prof_free;
+
 }  // namespace
 
+namespace dmr {
+StageScope::StageScope(int stage_, hipStream_t st_) : stage(stage_), st(st_), rec(nullptr) {
+    if (!(g_prof_mask.load(std::memory_order_relaxed) & (1u << stage))) return;
+    ProfRec* r = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+    }
+    if (!r) {
+        r = new ProfRec();
+        if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
+    }
+    r->stage = stage;
+    (void)hipEventRecord(r->a, st);
+    rec = r;
+}
+StageScope::~StageScope() {
+    if (!rec) return;
+    ProfRec* r = reinterpret_cast<ProfRec*>(rec);
+    (void)hipEventRecord(r->b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_live.push_back(r);
+}
+}  // namespace dmr
+
 extern "C" {
+
+void dmr_profile_enable(uint32_t mask) { g_prof_mask.store(mask); }
+
+int dmr_profile_collect(double* ms, int64_t* launches) {
+    std::vector<ProfRec*> live;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        live.swap(g_prof_live);
+    }
+    int rc = 0;
+    for (ProfRec* r : live) {
+        float t = 0.f;
+        if (hipEventSynchronize(r->b) != hipSuccess || hipEventElapsedTime(&t, r->a, r->b) != hipSuccess) {
+            g_err = "profile event read failed";
+            rc = 1;
+        } else if (r->stage >= 0 && r->stage < DMR_NUM_STAGES) {
+            if (ms) ms[r->stage] += (double)t;
+            if (launches) launches[r->stage] += 1;
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (ProfRec* r : live) g_prof_free.push_back(r);
+    return rc;
+}
+
+const char* dmr_stage_name(int stage) {
+    static const char* names[DMR_NUM_STAGES] = {"k_project_verts", "k_setup_faces", "k_scan_tiles", "k_scatter_faces",
+                                                "k_sort_tiles", "k_tri_forward", "k_tri_backward", "k_tri_unpack",
+                                                "k_tet_first_intersect", "k_tet_forward", "k_tet_backward"};
+    return (stage >= 0 && stage < DMR_NUM_STAGES) ? names[stage] : "?";
+}
 
 const char* dmr_last_error(void) { return g_err.c_str(); }
 int dmr_abi_version(void) { return DMR_ABI_VERSION; }

@@ -210,6 +210,7 @@ k_sort_tiles(const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ ke
 void launch_project_verts(const dmr_scene& s, float4* vproj, hipStream_t st) {
     const int64_t n = (int64_t)s.B * s.P;
     if (n == 0) return;
+    StageScope t(DMR_STAGE_PROJECT, st);
     k_project_verts<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
         s.B, s.P, s.verts, s.mv_mats, s.proj_mats, s.verts_depth, s.W, s.H, vproj);
 }
@@ -220,6 +221,7 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    StageScope t(DMR_STAGE_SETUP_FACES, st);
     if (tet)
         k_setup_faces<true><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect,
                                                     key_depth, max_depth, tiles_touched, tile_count);
@@ -230,6 +232,7 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
 
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
                        int* num_rendered, hipStream_t st) {
+    StageScope t(DMR_STAGE_SCAN, st);
     k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered);
 }
 
@@ -238,12 +241,14 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
                           hipStream_t st) {
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
+    StageScope t(DMR_STAGE_SCATTER, st);
     k_scatter_faces<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
         s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
 }
 
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, hipStream_t st) {
     if (ntiles == 0) return;
+    StageScope t(DMR_STAGE_SORT, st);
     k_sort_tiles<<<dim3((unsigned)ntiles), dim3(256), 0, st>>>(tile_offset, keys, face_list);
 }
 

@@ -17,6 +17,13 @@ namespace dmr {
 constexpr int VROW = 8;
 constexpr int FROW = 2;
 
+// ---- per-stage HIP-event timing (dmr_api.hip); a no-op unless dmr_profile_enable() set the stage's bit
+struct StageScope {
+    int stage; hipStream_t st; void* rec;
+    StageScope(int stage, hipStream_t st);
+    ~StageScope();
+};
+
 // ---- binning (dmr_binning.hip)
 void launch_project_verts(const dmr_scene& s, float4* vproj, hipStream_t st);
 void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int gx, int gy, int r0, int r1,

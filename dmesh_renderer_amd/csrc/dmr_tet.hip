@@ -319,6 +319,7 @@ void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int 
                                 TetImageState img, hipStream_t st) {
     if (r1 <= r0) return;
     TetParams p = make_params(s, gx, gy, r0, img);
+    StageScope t(DMR_STAGE_TET_FIRST, st);
     k_tet_first_intersect<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, key_depth, max_depth, tile_offset, face_list);
 }
 
@@ -326,6 +327,7 @@ void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetI
                         float* out_color, float* out_depth, float* out_active, hipStream_t st) {
     if (r1 <= r0) return;
     TetParams p = make_params(s, gx, gy, r0, img);
+    StageScope t(DMR_STAGE_TET_FORWARD, st);
     k_tet_forward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, out_color, out_depth, out_active);
 }
 
@@ -334,6 +336,7 @@ void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, Tet
                          hipStream_t st) {
     if (r1 <= r0) return;
     TetParams p = make_params(s, gx, gy, r0, img);
+    StageScope t(DMR_STAGE_TET_BACKWARD, st);
     k_tet_backward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity);
 }
 

@@ -22,15 +22,22 @@
 // hit's 23 gradient components into per-face LDS accumulators (ds_add_f32), and flushes a
 // chunk with packed atomics: 3 vertex rows + 1 face row per (tile, face) instead of the
 // reference's 23 global atomics per (pixel, face).
+#include <cstdlib>
+
 #include "dmr_kernels.hpp"
 
 namespace dmr {
 
 constexpr int FWD_CHUNK = 128;
-constexpr int BWD_CHUNK = 128;
+constexpr int BWD_CHUNK = 64;
 
+// s_i(x, y) = s0[i] + bx[i] * (x - x0) + by[i] * (y - y0) (mod 2^32), inside iff all three < 0.
+// A zero-area face (in_tri returns false, auxiliary.h:201-202) and the padding entries of a
+// partially filled 32-face word are stored as the all-zero record, which covers nothing.
+// `big` != 0: some bx/by does not fit a signed 24-bit operand (an edge longer than 32768 px), so the
+// chunk must use full 32-bit multiplies instead of v_mad_i32_i24.
 struct alignas(16) CovRec {
-    int32_t s0[3]; int32_t ok;
+    int32_t s0[3]; int32_t big;
     int32_t bx[3]; int32_t pad0;
     int32_t by[3]; int32_t pad1;
 };
@@ -47,15 +54,16 @@ struct alignas(16) ShadeRec {
 static_assert(sizeof(ShadeRec) == 112, "ShadeRec");
 
 struct TriParams {
-    int B, P, F, W, H, gx, gy, r0;
+    int B, P, F, W, H, gx, gy, r0, dbg;
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* inv_mv; const float* inv_proj; const float* faces_intense; const float* bg;
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
 };
 
-__device__ __forceinline__ void stage_face(const TriParams& p, int b, int face, int x0, int y0, V3 ray_o,
-                                           CovRec& cov, ShadeRec& sh, int* vid) {
+// returns cov.big
+__device__ __forceinline__ int stage_face(const TriParams& p, int b, int face, int x0, int y0, V3 ray_o,
+                                          CovRec& cov, ShadeRec& sh, int* vid) {
     const int v0 = p.faces[3 * face], v1 = p.faces[3 * face + 1], v2 = p.faces[3 * face + 2];
     const float4 a0 = p.vproj[(int64_t)b * p.P + v0];
     const float4 a1 = p.vproj[(int64_t)b * p.P + v1];
@@ -63,9 +71,13 @@ __device__ __forceinline__ void stage_face(const TriParams& p, int b, int face, 
     const V3 p0 = load_v3(p.verts, v0), p1 = load_v3(p.verts, v1), p2 = load_v3(p.verts, v2);
     const V3 c0 = load_v3(p.verts_color, v0), c1 = load_v3(p.verts_color, v1), c2 = load_v3(p.verts_color, v2);
     EdgeSetup e = edge_setup({a0.x, a0.y}, {a1.x, a1.y}, {a2.x, a2.y}, x0, y0);
+    int big = 0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { cov.s0[i] = e.s0[i]; cov.bx[i] = e.bx[i]; cov.by[i] = e.by[i]; }
-    cov.ok = e.ok ? 1 : 0;
+    for (int i = 0; i < 3; i++) {
+        cov.s0[i] = e.ok ? e.s0[i] : 0; cov.bx[i] = e.ok ? e.bx[i] : 0; cov.by[i] = e.ok ? e.by[i] : 0;
+        big |= (cov.bx[i] != ((cov.bx[i] << 8) >> 8)) | (cov.by[i] != ((cov.by[i] << 8) >> 8));
+    }
+    cov.big = big; cov.pad0 = 0; cov.pad1 = 0;
     const V3 T = ray_o - p0, E1 = p1 - p0, E2 = p2 - p0;
     const V3 Q = cross(T, E1);
     sh.T[0] = T.x; sh.T[1] = T.y; sh.T[2] = T.z;
@@ -79,25 +91,59 @@ __device__ __forceinline__ void stage_face(const TriParams& p, int b, int face, 
     sh.opacity = p.faces_opacity[face];
     sh.intense = p.faces_intense[(int64_t)b * p.F + face];
     if (vid) { vid[0] = v0; vid[1] = v1; vid[2] = v2; vid[3] = face; }
+    return big;
 }
 
-// phase A for one 32-face word of the chunk
-__device__ __forceinline__ uint32_t coverage_word(const CovRec* __restrict__ cov, int count, int lx, int ly) {
-    uint32_t m = 0;
-    for (int j = 0; j < count; j++) {
-        const CovRec& c = cov[j];
-        bool in = edge_inside(c.s0, c.bx, c.by, lx, ly) && (c.ok != 0);
-        m |= in ? (1u << j) : 0u;
+__device__ __forceinline__ void stage_null(CovRec& cov) {
+    int4* q = reinterpret_cast<int4*>(&cov);
+    q[0] = make_int4(0, 0, 0, 0); q[1] = make_int4(0, 0, 0, 0); q[2] = make_int4(0, 0, 0, 0);
+}
+
+// Phase A.  Reading a face's 36-byte coverage record is a wave-wide LDS broadcast that occupies
+// the CU's single LDS pipe for 12 cycles whoever asks, so letting all four waves of the tile read
+// every record made the kernel LDS-issue bound (measured: 157 of 232 us at C4).  Instead the chunk
+// is split into four blocks of NB consecutive faces and wave w evaluates block w for ALL 256 pixels:
+// each lane covers its pixel position in the four 8x8 quadrants (edge values of the other three
+// quadrants are one v_lshl_add_u32 away: + 8*bx, + 8*by).  mq[q] bit i = face (block w, i) covers
+// this lane's pixel of quadrant q.  The masks then change hands through LDS (s_mx).
+template <bool BIG, int NB>
+__device__ __forceinline__ void coverage_block(const CovRec* __restrict__ cov, int count, int lane, uint32_t mq[4]) {
+    const int lx = lane & 7, ly = lane >> 3;
+    mq[0] = mq[1] = mq[2] = mq[3] = 0;
+    const int rounds = (count + 3) >> 2;  // records beyond `count` inside the last group of 4 are null records
+    for (int j4 = 0; j4 < rounds; j4++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = 4 * j4 + u;
+            const CovRec& c = cov[j];
+            uint32_t e[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                if (BIG) e[i] = (uint32_t)c.s0[i] + (uint32_t)c.bx[i] * (uint32_t)lx + (uint32_t)c.by[i] * (uint32_t)ly;
+                else e[i] = (uint32_t)(__mul24(c.by[i], ly) + (__mul24(c.bx[i], lx) + c.s0[i]));
+            }
+            const uint32_t bit = 1u << j;
+            uint32_t t0 = e[0] & e[1] & e[2];
+            uint32_t t1 = (e[0] + ((uint32_t)c.bx[0] << 3)) & (e[1] + ((uint32_t)c.bx[1] << 3)) & (e[2] + ((uint32_t)c.bx[2] << 3));
+            uint32_t t2 = (e[0] + ((uint32_t)c.by[0] << 3)) & (e[1] + ((uint32_t)c.by[1] << 3)) & (e[2] + ((uint32_t)c.by[2] << 3));
+            uint32_t t3 = (e[0] + ((uint32_t)c.bx[0] << 3) + ((uint32_t)c.by[0] << 3)) & (e[1] + ((uint32_t)c.bx[1] << 3) + ((uint32_t)c.by[1] << 3))
+                        & (e[2] + ((uint32_t)c.bx[2] << 3) + ((uint32_t)c.by[2] << 3));
+            mq[0] |= ((int32_t)t0 < 0) ? bit : 0u;
+            mq[1] |= ((int32_t)t1 < 0) ? bit : 0u;
+            mq[2] |= ((int32_t)t2 < 0) ? bit : 0u;
+            mq[3] |= ((int32_t)t3 < 0) ? bit : 0u;
+        }
     }
-    return m;
 }
 
 template <int CHUNK>
 __global__ void __launch_bounds__(256)
 k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ out_depth) {
     constexpr int WORDS = CHUNK / 32;
+    static_assert(WORDS == 4, "one 32-face block per wave");
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
+    __shared__ uint32_t s_mx[4][4][64];  // [quadrant][face block = evaluating wave][lane]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
@@ -121,17 +167,27 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     for (uint32_t base = begin; base < end; base += CHUNK) {
         if (__syncthreads_and(done)) break;  // also fences LDS reuse
         const int n = (int)min((uint32_t)CHUNK, end - base);
-        if (tid < n) stage_face(p, b, (int)p.face_list[base + tid], tx * TILE, ty * TILE, view_o,
-                                s_cov[tid], s_shade[tid], nullptr);
-        __syncthreads();
-        if (__all(done)) continue;  // wave-uniform
+        int big = 0;
+        if (tid < n && !(p.dbg & 32)) big = stage_face(p, b, (int)p.face_list[base + tid], tx * TILE, ty * TILE, view_o,
+                                      s_cov[tid], s_shade[tid], nullptr);
+        else if (tid < ((n + 31) & ~31)) stage_null(s_cov[tid]);
+        const bool any_big = __syncthreads_or(big);
 
+        // A: this wave evaluates faces [32*wave, 32*wave+32) of the chunk for the whole tile
+        {
+            uint32_t mq[4];
+            const int cnt = (p.dbg & 16) ? 0 : min(32, max(0, n - 32 * wave));
+            if (any_big) coverage_block<true, 32>(s_cov + 32 * wave, cnt, lane, mq);
+            else coverage_block<false, 32>(s_cov + 32 * wave, cnt, lane, mq);
+#pragma unroll
+            for (int q = 0; q < 4; q++) s_mx[q][wave][lane] = mq[q];
+        }
+        __syncthreads();
         uint32_t m[WORDS];
 #pragma unroll
         for (int w = 0; w < WORDS; w++) {
-            const int cnt = min(32, max(0, n - 32 * w));
-            m[w] = coverage_word(s_cov + 32 * w, cnt, lx, ly);
-            if (done) m[w] = 0;
+            m[w] = s_mx[wave][w][lane];
+            if (done || (p.dbg & 8)) m[w] = 0;
         }
         while (true) {
             int w = -1; uint32_t mw = 0;
@@ -185,19 +241,47 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 
 // ---------------------------------------------------------------------------
 // backward
+//
+// Per chunk of 64 list entries (walked from the back of the tile list):
+//   A. coverage: as in the forward; every pixel thread gets a 64-bit mask `rem` of the chunk
+//      faces that cover it (positions >= its n_contrib masked off, backward.cu:192-194).
+//   B. per-pixel sequential part, in list order from the back: recover T (Q10), the running
+//      accum_rec terms and dL/dalpha (backward.cu:244-308).  Each pixel handles at most SLOTS
+//      hits per pass and parks (T, dL_dalpha) of hit #h in s_pool[pixel][h]; the pass mask of
+//      the pixel goes to s_pmask and, transposed by wave ballots, to s_cmask[face][quadrant].
+//   C. per-hit part, hit-parallel: the pass's hits are listed face-major (thread (face, quadrant)
+//      scatters its pixels into slots given by a block scan of the hit counts), then every lane
+//      takes ONE hit, recomputes the pixel-dependent geometry and the 23 gradient components of
+//      backward.cu:313-382, and a segmented wave scan (hits of a face are consecutive lanes)
+//      leaves each face's total in the last lane of its segment; only those lanes add into the
+//      per-face LDS sums (a handful of ds_add_f32 lanes per 64 hits instead of 23 per hit).
+//   After the last pass of a chunk the sums are flushed with packed global atomics: 3 vertex rows +
+//   1 face row per (tile, face) instead of the reference's 23 global atomics per (pixel, face)
+//   (backward.cu:389-418).
+// (Measured dead ends, kept out: 23 ds_add_f32 per hit -- 59 % of wave cycles stalled on LDS issue,
+//  LDS float atomics retire ~1 lane per 2.4 cycles; one thread per (face, quadrant) accumulating in
+//  registers -- no atomics but ~15 % lane utilisation on small triangles, 0.7 ms for C4.)
 // ---------------------------------------------------------------------------
 constexpr int NACC = 23;  // 9 dverts, 9 dvcolor, 3 dvdepth, dopacity, dintense
+constexpr int BWD_SLOTS = 8;
 
-template <int CHUNK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                float* __restrict__ vrow, float* __restrict__ frow) {
-    constexpr int WORDS = CHUNK / 32;
+    constexpr int CHUNK = 64;
+    static_assert(BWD_CHUNK == CHUNK, "phase C maps 4 quad lanes to each of 64 faces");
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
     __shared__ int s_vid[CHUNK][4];
-    __shared__ float s_acc[NACC][CHUNK];  // component-major: lanes on different faces hit different banks
+    __shared__ uint64_t s_cmask[CHUNK][4];       // [face][quadrant]: pixels of the quadrant that hit the face this pass
+    __shared__ uint64_t s_pmask[TILE_PIX];       // [pixel]: faces handled by the pixel this pass
+    __shared__ float2 s_pool[BWD_SLOTS][TILE_PIX];  // [hit ordinal from the back][pixel] = (T, dL_dalpha)
+    __shared__ float s_pix[7][TILE_PIX];         // ray d xyz, dL_dpixel rgb, dL_dpixel depth
+    __shared__ float s_acc[NACC][CHUNK];
     __shared__ uint32_t s_touched[CHUNK];
+    __shared__ uint32_t s_mx[4][4][64];          // [quadrant][face block = evaluating wave][lane], 16 faces per block
+    __shared__ uint16_t s_hits[TILE_PIX * BWD_SLOTS];  // face-major hit list of a pass: face << 8 | pixel
+    __shared__ int s_wsum[4];
     __shared__ uint32_t s_max_last;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -227,6 +311,8 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
         dpc2 = dL_dcolor[((int64_t)b * 3 + 2) * HW + pix_id];
         dpd = dL_ddepth[bpix];
     }
+    s_pix[0][tid] = rd.x; s_pix[1][tid] = rd.y; s_pix[2][tid] = rd.z;
+    s_pix[3][tid] = dpc0; s_pix[4][tid] = dpc1; s_pix[5][tid] = dpc2; s_pix[6][tid] = dpd;
     // backward.cu:293-298 (loop invariant there)
     float bg_dot = 0.f;
     bg_dot += p.bg[0] * dpc0; bg_dot += p.bg[1] * dpc1; bg_dot += p.bg[2] * dpc2;
@@ -236,141 +322,240 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_last, last_contributor);
     __syncthreads();
-    const uint32_t max_last = s_max_last;  // entries at list positions >= max_last contribute nowhere
-    if (max_last == 0) return;
+    const uint32_t total = s_max_last;  // list positions >= total contribute to no pixel of the tile
+    if (total == 0) return;
 
+    // pixel-thread state of the reverse walk
     float T = prev_T_final;
     bool first_pass = true;
     float acr0 = 0, acr1 = 0, acr2 = 0, acrd = 0;
     float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0;
 
-    const uint32_t total = max_last;                       // process list positions [0, total)
+    // face-thread identity for phase C
+    const int fk = tid >> 2, fq = tid & 3;
+
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
     for (uint32_t ci = 0; ci < nchunks; ci++) {
-        // chunk covers positions [lo, hi), taken from the back
-        const uint32_t hi = total - ci * CHUNK;
+        const uint32_t hi = total - ci * CHUNK;  // chunk = list positions [lo, hi)
         const uint32_t lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
         const int n = (int)(hi - lo);
-        __syncthreads();  // previous chunk's flush done before LDS reuse
-        if (tid < n) {
-            stage_face(p, b, (int)p.face_list[begin + lo + tid], tx * TILE, ty * TILE, view_o,
-                       s_cov[tid], s_shade[tid], s_vid[tid]);
-            s_touched[tid] = 0;
+        __syncthreads();  // previous chunk's flush is done with the LDS records
+        int big = 0;
+        if (tid < n)
+            big = stage_face(p, b, (int)p.face_list[begin + lo + tid], tx * TILE, ty * TILE, view_o,
+                             s_cov[tid], s_shade[tid], s_vid[tid]);
+        else if (tid < ((n + 31) & ~31)) stage_null(s_cov[tid]);
+        const bool any_big = __syncthreads_or(big);
+
+        // ---- A: wave w evaluates faces [16w, 16w+16) for the whole tile; masks change hands via s_mx
+        {
+            uint32_t mq[4];
+            const int cnt = min(16, max(0, n - 16 * wave));
+            if (any_big) coverage_block<true, 16>(s_cov + 16 * wave, cnt, lane, mq);
+            else coverage_block<false, 16>(s_cov + 16 * wave, cnt, lane, mq);
+#pragma unroll
+            for (int q = 0; q < 4; q++) s_mx[q][wave][lane] = mq[q];
         }
-        for (int i = tid; i < NACC * CHUNK; i += 256) (&s_acc[0][0])[i] = 0.f;
         __syncthreads();
-
-        uint32_t m[WORDS];
-#pragma unroll
-        for (int w = 0; w < WORDS; w++) {
-            const int cnt = min(32, max(0, n - 32 * w));
-            uint32_t mw = coverage_word(s_cov + 32 * w, cnt, lx, ly);
-            // keep only positions < last_contributor (backward.cu:192-194)
-            const int64_t lim = (int64_t)last_contributor - (int64_t)(lo + 32 * w);
-            if (lim <= 0) mw = 0;
-            else if (lim < 32) mw &= (1u << lim) - 1u;
-            m[w] = mw;
+        uint64_t rem;
+        {
+            rem = (uint64_t)s_mx[wave][0][lane] | ((uint64_t)s_mx[wave][1][lane] << 16)
+                | ((uint64_t)s_mx[wave][2][lane] << 32) | ((uint64_t)s_mx[wave][3][lane] << 48);
+            const int64_t lim = (int64_t)last_contributor - (int64_t)lo;  // keep positions < last_contributor
+            if (lim <= 0) rem = 0;
+            else if (lim < 64) rem &= (1ull << lim) - 1ull;
         }
-        while (true) {
-            int w = -1; uint32_t mw = 0;
-#pragma unroll
-            for (int q = 0; q < WORDS; q++) if (m[q]) { w = q; mw = m[q]; }
-            if (w < 0) break;
-            const int bit = 31 - __clz((int)mw);
-            const uint32_t clr = mw & ~(1u << bit);
-#pragma unroll
-            for (int q = 0; q < WORDS; q++) if (q == w) m[q] = clr;
-            const int k = 32 * w + bit;
-            const ShadeRec& r = s_shade[k];
 
-            const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
-            const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
-            const V3 Pv = cross(rd, E2);
-            const float denom = dot(Pv, E1);
-            if (denom == 0.0f) continue;
-            const float inv_denom = 1.0f / denom;
-            const float nu = dot(Pv, Tv);          // v0 of the grad helper
-            const float iu = nu * inv_denom;
-            const float iv = dot(Q, rd) * inv_denom;
-            float iuc, ivc; int code;
-            clamp_bary_uv(iu, iv, iuc, ivc, code);
-            const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
-            const float intense = r.intense;
-            const float c00 = r.c0[0], c01 = r.c0[1], c02 = r.c0[2];
-            const float c10 = r.c1[0], c11 = r.c1[1], c12 = r.c1[2];
-            const float c20 = r.c2[0], c21 = r.c2[1], c22 = r.c2[2];
-            const float iC0 = (i0 * c00 + i1 * c10 + i2 * c20) * intense;
-            const float iC1 = (i0 * c01 + i1 * c11 + i2 * c21) * intense;
-            const float iC2 = (i0 * c02 + i1 * c12 + i2 * c22) * intense;
-            const float iD = i0 * r.d0 + i1 * r.d1 + i2 * r.d2;
-            const float alpha = r.opacity;
+        // per-face sums of this chunk live in LDS; only segment tails touch them (see C2)
+        for (int i = tid; i < NACC * CHUNK; i += 256) (&s_acc[0][0])[i] = 0.f;
+        if (tid < CHUNK) s_touched[tid] = 0u;
 
-            if (!first_pass) T = T / (1.f - alpha);  // Q10
-            first_pass = false;
-
-            float dL_dalpha = 0.0f;
-            acr0 = last_alpha * lc0 + (1.f - last_alpha) * acr0; lc0 = iC0;
-            const float dic0 = dpc0 * alpha * T; dL_dalpha += (iC0 - acr0) * dpc0;
-            acr1 = last_alpha * lc1 + (1.f - last_alpha) * acr1; lc1 = iC1;
-            const float dic1 = dpc1 * alpha * T; dL_dalpha += (iC1 - acr1) * dpc1;
-            acr2 = last_alpha * lc2 + (1.f - last_alpha) * acr2; lc2 = iC2;
-            const float dic2 = dpc2 * alpha * T; dL_dalpha += (iC2 - acr2) * dpc2;
-            acrd = last_alpha * last_depth + (1.f - last_alpha) * acrd; last_depth = iD;
-            const float did = dpd * alpha * T; dL_dalpha += (iD - acrd) * dpd;
-            dL_dalpha *= T;
-            last_alpha = alpha;
-            if (alpha == 1.0f) {
-                dL_dalpha += (-prev_T_final) * bg_dot;
-                dL_dalpha += (-prev_T_final) * bd_dot;
-            } else {
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bd_dot;
+        while (__syncthreads_or(rem != 0ull)) {
+            // ---- B: up to BWD_SLOTS hits of this pixel, from the back
+            uint64_t pm = 0;
+            int h = 0;
+            if (p.dbg & 4) rem = 0ull;
+            while (rem != 0ull && h < BWD_SLOTS) {
+                const int k = 63 - __clzll((long long)rem);
+                const uint64_t bit = 1ull << k;
+                rem &= ~bit;
+                const ShadeRec& r = s_shade[k];
+                const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
+                const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
+                const V3 Pv = cross(rd, E2);
+                const float denom = dot(Pv, E1);
+                if (denom == 0.0f) continue;  // "edge case": skipped entirely (backward.cu:215-216)
+                const float inv_denom = 1.0f / denom;
+                const float iu = dot(Pv, Tv) * inv_denom;
+                const float iv = dot(Q, rd) * inv_denom;
+                float iuc, ivc; int code;
+                clamp_bary_uv(iu, iv, iuc, ivc, code);
+                const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
+                const float intense = r.intense;
+                const float iC0 = (i0 * r.c0[0] + i1 * r.c1[0] + i2 * r.c2[0]) * intense;
+                const float iC1 = (i0 * r.c0[1] + i1 * r.c1[1] + i2 * r.c2[1]) * intense;
+                const float iC2 = (i0 * r.c0[2] + i1 * r.c1[2] + i2 * r.c2[2]) * intense;
+                const float iD = i0 * r.d0 + i1 * r.d1 + i2 * r.d2;
+                const float alpha = r.opacity;
+                if (!first_pass) T = T / (1.f - alpha);  // Q10
+                first_pass = false;
+                float dL_dalpha = 0.0f;
+                acr0 = last_alpha * lc0 + (1.f - last_alpha) * acr0; lc0 = iC0; dL_dalpha += (iC0 - acr0) * dpc0;
+                acr1 = last_alpha * lc1 + (1.f - last_alpha) * acr1; lc1 = iC1; dL_dalpha += (iC1 - acr1) * dpc1;
+                acr2 = last_alpha * lc2 + (1.f - last_alpha) * acr2; lc2 = iC2; dL_dalpha += (iC2 - acr2) * dpc2;
+                acrd = last_alpha * last_depth + (1.f - last_alpha) * acrd; last_depth = iD;
+                dL_dalpha += (iD - acrd) * dpd;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                if (alpha == 1.0f) {
+                    dL_dalpha += (-prev_T_final) * bg_dot;
+                    dL_dalpha += (-prev_T_final) * bd_dot;
+                } else {
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bd_dot;
+                }
+                s_pool[h][tid] = make_float2(T, dL_dalpha);
+                pm |= bit;
+                h++;
             }
+            s_pmask[tid] = pm;
+            // transpose: for every face of the chunk, which pixels of this quadrant took it this pass
+            if (__any(pm != 0ull)) {
+                for (int j = 0; j < n; j++) {
+                    const uint64_t bal = __ballot((pm >> j) & 1ull);
+                    if (lane == 0) s_cmask[j][wave] = bal;
+                }
+            } else if (lane < n) {
+                s_cmask[lane][wave] = 0ull;
+            }
+            __syncthreads();
 
-            float dL_di0 = 0, dL_di1 = 0, dL_di2 = 0, dfint = 0;
-            dL_di0 += c00 * dic0 * intense; dL_di1 += c10 * dic0 * intense; dL_di2 += c20 * dic0 * intense;
-            const float g00 = i0 * dic0 * intense, g10 = i1 * dic0 * intense, g20 = i2 * dic0 * intense;
-            dfint += (i0 * c00 + i1 * c10 + i2 * c20) * dic0;
-            dL_di0 += c01 * dic1 * intense; dL_di1 += c11 * dic1 * intense; dL_di2 += c21 * dic1 * intense;
-            const float g01 = i0 * dic1 * intense, g11 = i1 * dic1 * intense, g21 = i2 * dic1 * intense;
-            dfint += (i0 * c01 + i1 * c11 + i2 * c21) * dic1;
-            dL_di0 += c02 * dic2 * intense; dL_di1 += c12 * dic2 * intense; dL_di2 += c22 * dic2 * intense;
-            const float g02 = i0 * dic2 * intense, g12 = i1 * dic2 * intense, g22 = i2 * dic2 * intense;
-            dfint += (i0 * c02 + i1 * c12 + i2 * c22) * dic2;
-            dL_di0 += r.d0 * did; dL_di1 += r.d1 * did; dL_di2 += r.d2 * did;
-            const float gd0 = i0 * did, gd1 = i1 * did, gd2 = i2 * did;
+            // ---- C1: face-major hit list of this pass.  Thread (fk, fq) owns the hits of face fk in
+            // quadrant fq; an exclusive block scan of the counts gives every hit a slot, so that
+            // consecutive slots belong to the same face.
+            uint64_t cm = (fk < n) ? s_cmask[fk][fq] : 0ull;
+            if (p.dbg & 2) cm = 0ull;
+            const int cnt = __popcll(cm);
+            int incl = cnt;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int o = __shfl_up(incl, dlt, 64);
+                if (lane >= dlt) incl += o;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            int hbase = incl - cnt;
+            int H = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int ws = s_wsum[w];
+                if (w < wave) hbase += ws;
+                H += ws;
+            }
+            while (cm != 0ull) {
+                const int l = __ffsll((long long)cm) - 1;
+                cm &= cm - 1ull;
+                s_hits[hbase++] = (uint16_t)((fk << 8) | (fq * 64 + l));
+            }
+            __syncthreads();
 
-            float duc_du, duc_dv, dvc_du, dvc_dv;
-            clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
-            const float di0_diu = -1.f * duc_du + -1.f * dvc_du, di0_div = -1.f * duc_dv + -1.f * dvc_dv;
-            const float di1_diu = 1.f * duc_du + 0.f * dvc_du, di1_div = 1.f * duc_dv + 0.f * dvc_dv;
-            const float di2_diu = 0.f * duc_du + 1.f * dvc_du, di2_div = 0.f * duc_dv + 1.f * dvc_dv;
-            const float dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
-            const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
+            // ---- C2: one hit per lane; 23 gradient components; segmented wave scan by face; the last
+            // lane of every segment adds the segment total into the per-face LDS sums.
+            for (int i0h = wave * 64; i0h < H; i0h += 256) {
+                const int hi_idx = i0h + lane;
+                const bool valid = hi_idx < H;
+                const uint32_t desc = valid ? (uint32_t)s_hits[hi_idx] : 0xffffu;
+                const int k = valid ? (int)(desc >> 8) : -1 - lane;  // invalid lanes: unique keys
+                float g[NACC];
+#pragma unroll
+                for (int c = 0; c < NACC; c++) g[c] = 0.f;
+                if (valid) {
+                    const int pp = (int)(desc & 0xffu);
+                    const ShadeRec& r = s_shade[k];
+                    const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
+                    const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
+                    const float c00 = r.c0[0], c01 = r.c0[1], c02 = r.c0[2];
+                    const float c10 = r.c1[0], c11 = r.c1[1], c12 = r.c1[2];
+                    const float c20 = r.c2[0], c21 = r.c2[1], c22 = r.c2[2];
+                    const float fd0 = r.d0, fd1 = r.d1, fd2 = r.d2, alpha = r.opacity, intense = r.intense;
+                    const uint64_t pmk = s_pmask[pp];
+                    const int ord = __popcll(k < 63 ? (pmk >> (k + 1)) : 0ull);  // hits of that pixel behind face k
+                    const float2 rec = s_pool[ord][pp];
+                    const V3 d = {s_pix[0][pp], s_pix[1][pp], s_pix[2][pp]};
+                    const float g0 = s_pix[3][pp], g1 = s_pix[4][pp], g2 = s_pix[5][pp], gdp = s_pix[6][pp];
+                    const float Th = rec.x;
 
-            // ray_tri_intersection_grad (auxiliary.h:288-333), Q11/Q12 kept
-            const float dsq = denom, den2 = dsq * dsq, dinv = 1.0f / den2;
-            const float v0 = nu, v1 = dsq, v2 = dot(Q, E2);
-            const V3 du_dE1 = (-1.0f * Pv * v0) * dinv;
-            const V3 du_dE2 = (cross(Tv, rd) * v1 - v0 * cross(E1, rd)) * dinv;
-            const V3 du_dT = (Pv * v1) * dinv;
-            const V3 dv_dE1 = ((cross(E2, Tv) * v1) - (v2 * Pv)) * dinv;
-            const V3 dv_dE2 = ((Q * v1) - (v2 * cross(E1, rd))) * dinv;
-            const V3 dv_dT = cross(E1, E2) * v1 * dinv;
-            const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
-            const V3 dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
-            const V3 dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
-            const V3 dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
+                    const V3 Pv = cross(d, E2);
+                    const float denom = dot(Pv, E1);
+                    const float inv_denom = 1.0f / denom;
+                    const float nu = dot(Pv, Tv);
+                    const float iu = nu * inv_denom;
+                    const float iv = dot(Q, d) * inv_denom;
+                    float iuc, ivc; int code;
+                    clamp_bary_uv(iu, iv, iuc, ivc, code);
+                    const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
+                    const float dic0 = g0 * alpha * Th, dic1 = g1 * alpha * Th, dic2 = g2 * alpha * Th;
+                    const float did = gdp * alpha * Th;
 
-            atomicAdd(&s_acc[0][k], dp0.x); atomicAdd(&s_acc[1][k], dp0.y); atomicAdd(&s_acc[2][k], dp0.z);
-            atomicAdd(&s_acc[3][k], dp1.x); atomicAdd(&s_acc[4][k], dp1.y); atomicAdd(&s_acc[5][k], dp1.z);
-            atomicAdd(&s_acc[6][k], dp2.x); atomicAdd(&s_acc[7][k], dp2.y); atomicAdd(&s_acc[8][k], dp2.z);
-            atomicAdd(&s_acc[9][k], g00); atomicAdd(&s_acc[10][k], g01); atomicAdd(&s_acc[11][k], g02);
-            atomicAdd(&s_acc[12][k], g10); atomicAdd(&s_acc[13][k], g11); atomicAdd(&s_acc[14][k], g12);
-            atomicAdd(&s_acc[15][k], g20); atomicAdd(&s_acc[16][k], g21); atomicAdd(&s_acc[17][k], g22);
-            atomicAdd(&s_acc[18][k], gd0); atomicAdd(&s_acc[19][k], gd1); atomicAdd(&s_acc[20][k], gd2);
-            atomicAdd(&s_acc[21][k], dL_dalpha); atomicAdd(&s_acc[22][k], dfint);
-            s_touched[k] = 1u;
+                    float dL_di0 = 0, dL_di1 = 0, dL_di2 = 0, dfint = 0;
+                    dL_di0 += c00 * dic0 * intense; dL_di1 += c10 * dic0 * intense; dL_di2 += c20 * dic0 * intense;
+                    dfint += (i0 * c00 + i1 * c10 + i2 * c20) * dic0;
+                    dL_di0 += c01 * dic1 * intense; dL_di1 += c11 * dic1 * intense; dL_di2 += c21 * dic1 * intense;
+                    dfint += (i0 * c01 + i1 * c11 + i2 * c21) * dic1;
+                    dL_di0 += c02 * dic2 * intense; dL_di1 += c12 * dic2 * intense; dL_di2 += c22 * dic2 * intense;
+                    dfint += (i0 * c02 + i1 * c12 + i2 * c22) * dic2;
+                    dL_di0 += fd0 * did; dL_di1 += fd1 * did; dL_di2 += fd2 * did;
+
+                    float duc_du, duc_dv, dvc_du, dvc_dv;
+                    clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
+                    const float di0_diu = -1.f * duc_du + -1.f * dvc_du, di0_div = -1.f * duc_dv + -1.f * dvc_dv;
+                    const float di1_diu = 1.f * duc_du + 0.f * dvc_du, di1_div = 1.f * duc_dv + 0.f * dvc_dv;
+                    const float di2_diu = 0.f * duc_du + 1.f * dvc_du, di2_div = 0.f * duc_dv + 1.f * dvc_dv;
+                    const float dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
+                    const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
+
+                    // ray_tri_intersection_grad (auxiliary.h:288-333), Q11/Q12 kept
+                    const float dsq = denom, den2 = dsq * dsq, dinv = 1.0f / den2;
+                    const float v0 = nu, v1 = dsq, v2 = dot(Q, E2);
+                    const V3 du_dE1 = (-1.0f * Pv * v0) * dinv;
+                    const V3 du_dE2 = (cross(Tv, d) * v1 - v0 * cross(E1, d)) * dinv;
+                    const V3 du_dT = (Pv * v1) * dinv;
+                    const V3 dv_dE1 = ((cross(E2, Tv) * v1) - (v2 * Pv)) * dinv;
+                    const V3 dv_dE2 = ((Q * v1) - (v2 * cross(E1, d))) * dinv;
+                    const V3 dv_dT = cross(E1, E2) * v1 * dinv;
+                    const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
+                    const V3 dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
+                    const V3 dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
+                    const V3 dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
+
+                    g[0] = dp0.x; g[1] = dp0.y; g[2] = dp0.z;
+                    g[3] = dp1.x; g[4] = dp1.y; g[5] = dp1.z;
+                    g[6] = dp2.x; g[7] = dp2.y; g[8] = dp2.z;
+                    g[9] = i0 * dic0 * intense; g[10] = i0 * dic1 * intense; g[11] = i0 * dic2 * intense;
+                    g[12] = i1 * dic0 * intense; g[13] = i1 * dic1 * intense; g[14] = i1 * dic2 * intense;
+                    g[15] = i2 * dic0 * intense; g[16] = i2 * dic1 * intense; g[17] = i2 * dic2 * intense;
+                    g[18] = i0 * did; g[19] = i1 * did; g[20] = i2 * did;
+                    g[21] = rec.y; g[22] = dfint;
+                }
+                // segmented inclusive scan: hits of one face are consecutive lanes
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    const int ko = __shfl_up(k, dlt, 64);
+                    const bool same = (lane >= dlt) && (ko == k);
+#pragma unroll
+                    for (int c = 0; c < NACC; c++) {
+                        const float o = __shfl_up(g[c], dlt, 64);
+                        g[c] += same ? o : 0.f;
+                    }
+                }
+                const int kn = __shfl_down(k, 1, 64);
+                if (valid && (lane == 63 || kn != k)) {  // segment tail holds the segment total
+#pragma unroll
+                    for (int c = 0; c < NACC; c++) atomicAdd(&s_acc[c][k], g[c]);
+                    s_touched[k] = 1u;
+                }
+            }
+            // the loop-top __syncthreads_or keeps pass k+1 from overwriting s_pool/s_pmask/s_cmask/s_hits early
         }
         __syncthreads();
 
@@ -378,15 +563,13 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
         const int sub = tid & 31, grp = sub >> 3, comp = sub & 7;
         for (int f0 = 0; f0 < n; f0 += 8) {
             const int k = f0 + (tid >> 5);
-            if (k >= n || !s_touched[k]) continue;
+            if (k >= n || !s_touched[k] || (p.dbg & 1)) continue;
             if (grp < 3) {
                 if (comp == 7) continue;
                 const int ai = comp < 3 ? grp * 3 + comp : (comp < 6 ? 9 + grp * 3 + (comp - 3) : 18 + grp);
-                const float v = s_acc[ai][k];
-                atomicAdd(&vrow[((int64_t)b * p.P + s_vid[k][grp]) * VROW + comp], v);
+                atomicAdd(&vrow[((int64_t)b * p.P + s_vid[k][grp]) * VROW + comp], s_acc[ai][k]);
             } else if (comp < 2) {
-                const float v = s_acc[21 + comp][k];
-                atomicAdd(&frow[((int64_t)b * p.F + s_vid[k][3]) * FROW + comp], v);
+                atomicAdd(&frow[((int64_t)b * p.F + s_vid[k][3]) * FROW + comp], s_acc[21 + comp][k]);
             }
         }
     }
@@ -424,6 +607,7 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, const f
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img) {
     TriParams p;
     p.B = s.B; p.P = s.P; p.F = s.F; p.W = s.W; p.H = s.H; p.gx = gx; p.gy = gy; p.r0 = r0;
+    { static const int dbg = getenv("DMR_ABLATE") ? atoi(getenv("DMR_ABLATE")) : 0; p.dbg = dbg; }  // timing ablations only
     p.verts = s.verts; p.faces = s.faces; p.verts_color = s.verts_color; p.faces_opacity = s.faces_opacity;
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;
@@ -436,6 +620,7 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
                         float* out_color, float* out_depth, hipStream_t st) {
     if (r1 <= r0) return;
     TriParams p = make_params(s, gx, gy, r0, vproj, tile_offset, face_list, img);
+    StageScope t(DMR_STAGE_TRI_FORWARD, st);
     k_tri_forward<FWD_CHUNK><<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, out_color, out_depth);
 }
 
@@ -444,7 +629,8 @@ void launch_tri_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, con
                          const float* dL_dcolor, const float* dL_ddepth, float* vrow, float* frow, hipStream_t st) {
     if (r1 <= r0) return;
     TriParams p = make_params(s, gx, gy, r0, vproj, tile_offset, face_list, img);
-    k_tri_backward<BWD_CHUNK><<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, vrow, frow);
+    StageScope t(DMR_STAGE_TRI_BACKWARD, st);
+    k_tri_backward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, vrow, frow);
 }
 
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
@@ -452,6 +638,7 @@ void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow,
                        hipStream_t st) {
     const int64_t n = s.P > s.F ? s.P : s.F;
     if (n == 0) return;
+    StageScope t(DMR_STAGE_TRI_UNPACK, st);
     k_tri_unpack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
         s.B, s.P, s.F, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense);
 }

@@ -196,3 +196,32 @@ def make(config: str, seed: int = 0, **over) -> Dict[str, th.Tensor]:
                               opacity=over.get("opacity", (0.1, 0.5)))
     return kuhn_tets(over.get("n", c.n), over.get("B", c.B), over.get("H", c.H), over.get("W", c.W),
                      seed=seed, opacity=over.get("opacity", (0.02, 0.3)))
+
+
+def c_args(d: Dict[str, th.Tensor], device=None, tet: bool = False):
+    """Scene dict (row-major matrices) -> the leading tensor arguments of `_C.render_tris` /
+    `_C.render_tets`: transposed mv/proj and their inverses, as the reference wrapper passes them
+    (dmesh_renderer/__init__.py:62-63,219-220)."""
+    mv_t = d["mv_mats"].transpose(1, 2)
+    proj_t = d["proj_mats"].transpose(1, 2)
+    inv_mv, inv_proj = th.inverse(mv_t), th.inverse(proj_t)
+    args = [d["bg"], d["verts"], d["faces"], d["verts_color"], d["faces_opacity"], mv_t, proj_t, inv_mv, inv_proj,
+            d["verts_depth"], d["faces_intense"]]
+    if tet:
+        args += [d["tets"], d["face_tets"], d["tet_faces"]]
+    if device is not None:
+        args = [a.to(device) for a in args]
+    return args
+
+
+def upstream_grads(B: int, H: int, W: int, seed: int = 1):
+    """dL/dcolor [B,3,H,W], dL/ddepth [B,1,H,W] ~ N(0,1), seeded."""
+    g = th.Generator().manual_seed(seed)
+    return th.randn(B, 3, H, W, generator=g), th.randn(B, 1, H, W, generator=g)
+
+
+def rel_err(got: np.ndarray, ref: np.ndarray) -> float:
+    """max-abs(got - ref) / max(1, max-abs(ref)): the gradient error of the metric."""
+    if ref.size == 0:
+        return 0.0
+    return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / max(1.0, float(np.abs(ref).max())))

@@ -103,6 +103,19 @@ int64_t dmr_export(const dmr_scene* scene, int is_tet, int num_rendered, const c
                    const void* point_buf, const void* face_buf, const void* binning_buf,
                    const void* image_buf, void* dst, int64_t cap, void* stream);
 
+/* Per-stage device timing with HIP events recorded on the caller's stream (bench.py's roofline
+ * leg).  `mask` has bit i set to time stage i; 0 disables (the default: no events recorded). */
+enum {
+    DMR_STAGE_PROJECT = 0, DMR_STAGE_SETUP_FACES = 1, DMR_STAGE_SCAN = 2, DMR_STAGE_SCATTER = 3,
+    DMR_STAGE_SORT = 4, DMR_STAGE_TRI_FORWARD = 5, DMR_STAGE_TRI_BACKWARD = 6, DMR_STAGE_TRI_UNPACK = 7,
+    DMR_STAGE_TET_FIRST = 8, DMR_STAGE_TET_FORWARD = 9, DMR_STAGE_TET_BACKWARD = 10, DMR_NUM_STAGES = 11
+};
+void dmr_profile_enable(uint32_t mask);
+/* Waits for the recorded events, ADDS each stage's elapsed milliseconds / launch count into
+ * ms[DMR_NUM_STAGES] / launches[DMR_NUM_STAGES] and clears the records.  Returns 0 on success. */
+int dmr_profile_collect(double* ms, int64_t* launches);
+const char* dmr_stage_name(int stage);
+
 const char* dmr_last_error(void);
 int dmr_abi_version(void);
 /* Name of the code object architecture the library was built for ("gfx950"). */
