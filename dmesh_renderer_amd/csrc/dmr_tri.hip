@@ -265,7 +265,34 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 constexpr int NACC = 23;  // 9 dverts, 9 dvcolor, 3 dvdepth, dopacity, dintense
 constexpr int BWD_SLOTS = 8;
 
-__global__ void __launch_bounds__(256, 4)
+// DPP lane moves (VALU, no LDS traffic).  A lane whose source is outside its 16-lane row (row_shr)
+// or outside the written rows (row_bcast, row_mask) keeps `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int DPP_ROW_SHR = 0x110;      // + n, n = 1..15
+constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of the next row
+constexpr int DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
+
+// one level of the segmented inclusive scan over the 23 components: lanes whose source lane carries the
+// same face key add the source's partial sum
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
+    const int ko = dpp_i<CTRL, ROW_MASK>((int)0x80000000, k);
+    const bool same = (ko == k);
+#pragma unroll
+    for (int c = 0; c < NACC; c++) {
+        const float o = dpp_f<CTRL, ROW_MASK>(0.f, g[c]);
+        g[c] += same ? o : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256, 3)
 k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                float* __restrict__ vrow, float* __restrict__ frow) {
     constexpr int CHUNK = 64;
@@ -279,9 +306,13 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
     __shared__ float s_pix[7][TILE_PIX];         // ray d xyz, dL_dpixel rgb, dL_dpixel depth
     __shared__ float s_acc[NACC][CHUNK];
     __shared__ uint32_t s_touched[CHUNK];
-    __shared__ uint32_t s_mx[4][4][64];          // [quadrant][face block = evaluating wave][lane], 16 faces per block
-    __shared__ uint16_t s_hits[TILE_PIX * BWD_SLOTS];  // face-major hit list of a pass: face << 8 | pixel
+    // s_mx (phase A hand-off) and s_hits (phase C hit list) are never live together: one buffer
+    __shared__ uint32_t s_mx_hits[4 * 4 * 64];
+    uint32_t (*s_mx)[4][64] = reinterpret_cast<uint32_t (*)[4][64]>(s_mx_hits);  // [quadrant][face block][lane]
+    uint16_t* s_hits = reinterpret_cast<uint16_t*>(s_mx_hits);  // face-major hit list of a pass: face << 8 | pixel
+    static_assert(sizeof(uint16_t) * TILE_PIX * BWD_SLOTS <= sizeof(uint32_t) * 4 * 4 * 64, "hit list fits");
     __shared__ int s_wsum[4];
+    __shared__ int s_fstart[64 + 1];
     __shared__ uint32_t s_max_last;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -452,6 +483,8 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
                 if (w < wave) hbase += ws;
                 H += ws;
             }
+            if (fq == 0) s_fstart[fk] = hbase;  // first hit slot of face fk (4 quadrant runs follow each other)
+            if (tid == 0) s_fstart[CHUNK] = H;
             while (cm != 0ull) {
                 const int l = __ffsll((long long)cm) - 1;
                 cm &= cm - 1ull;
@@ -461,15 +494,18 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
 
             // ---- C2: one hit per lane; 23 gradient components; segmented wave scan by face; the last
             // lane of every segment adds the segment total into the per-face LDS sums.
-            for (int i0h = wave * 64; i0h < H; i0h += 256) {
+            // wave w owns faces [16w, 16w+16): no other wave touches their LDS sums, so segment tails can
+            // use plain read-modify-write instead of ds_add_f32
+            const int h_end = s_fstart[16 * wave + 16];
+            for (int i0h = s_fstart[16 * wave]; i0h < h_end; i0h += 64) {
                 const int hi_idx = i0h + lane;
-                const bool valid = hi_idx < H;
+                const bool valid = hi_idx < h_end;
                 const uint32_t desc = valid ? (uint32_t)s_hits[hi_idx] : 0xffffu;
                 const int k = valid ? (int)(desc >> 8) : -1 - lane;  // invalid lanes: unique keys
                 float g[NACC];
 #pragma unroll
                 for (int c = 0; c < NACC; c++) g[c] = 0.f;
-                if (valid) {
+                if (valid && !(p.dbg & 128)) {
                     const int pp = (int)(desc & 0xffu);
                     const ShadeRec& r = s_shade[k];
                     const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
@@ -537,21 +573,20 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
                     g[18] = i0 * did; g[19] = i1 * did; g[20] = i2 * did;
                     g[21] = rec.y; g[22] = dfint;
                 }
-                // segmented inclusive scan: hits of one face are consecutive lanes
-#pragma unroll
-                for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                    const int ko = __shfl_up(k, dlt, 64);
-                    const bool same = (lane >= dlt) && (ko == k);
-#pragma unroll
-                    for (int c = 0; c < NACC; c++) {
-                        const float o = __shfl_up(g[c], dlt, 64);
-                        g[c] += same ? o : 0.f;
-                    }
+                // segmented inclusive scan over the wave (hits of one face are consecutive lanes): four
+                // row-local DPP levels, then the two row-broadcast levels of the classic wave scan
+                if (!(p.dbg & 64)) {
+                    seg_scan_level<DPP_ROW_SHR + 1, 0xF>(k, g);
+                    seg_scan_level<DPP_ROW_SHR + 2, 0xF>(k, g);
+                    seg_scan_level<DPP_ROW_SHR + 4, 0xF>(k, g);
+                    seg_scan_level<DPP_ROW_SHR + 8, 0xF>(k, g);
+                    seg_scan_level<DPP_ROW_BCAST15, 0xA>(k, g);
+                    seg_scan_level<DPP_ROW_BCAST31, 0xC>(k, g);
                 }
                 const int kn = __shfl_down(k, 1, 64);
-                if (valid && (lane == 63 || kn != k)) {  // segment tail holds the segment total
+                if (valid && (lane == 63 || kn != k) && !(p.dbg & 256)) {  // segment tail holds the segment total
 #pragma unroll
-                    for (int c = 0; c < NACC; c++) atomicAdd(&s_acc[c][k], g[c]);
+                    for (int c = 0; c < NACC; c++) s_acc[c][k] += g[c];
                     s_touched[k] = 1u;
                 }
             }
