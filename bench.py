@@ -45,19 +45,6 @@ def parse():
     return ap.parse_args()
 
 
-def balanced_bands(row_work: np.ndarray, n: int):
-    """Split tile rows into n contiguous bands of (nearly) equal work."""
-    w = row_work.astype(np.float64) + 1e-3  # empty rows still cost a launch
-    cum = np.concatenate([[0.0], np.cumsum(w)])
-    cuts = [0]
-    for k in range(1, n):
-        cuts.append(int(np.searchsorted(cum, cum[-1] * k / n)))
-    cuts.append(len(row_work))
-    for i in range(1, len(cuts)):
-        cuts[i] = max(cuts[i], cuts[i - 1])
-    return [(cuts[i], cuts[i + 1]) for i in range(n)]
-
-
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,6 +60,7 @@ def main():
 
     from dmesh_renderer_amd import _C, _lib, scenes
     from dmesh_renderer_amd.scenes import c_args, rel_err, upstream_grads
+    from dmesh_renderer_amd.sharding import balanced_bands, row_work_from_ranges
 
     cfg = scenes.CONFIGS[a.config]
     d = scenes.make(a.config)
@@ -89,9 +77,8 @@ def main():
     out = _C.render_tris(*args, H, W)
     R_full = out[0]
     if world > 1:
-        ranges = _C.export("ranges", args, False, out[0], out[3:7], H, W, th.int32).cpu().numpy().reshape(B, gy, gx, 2)
-        row_work = (ranges[..., 1] - ranges[..., 0]).sum(axis=(0, 2))
-        rows = balanced_bands(row_work, world)[rank]
+        ranges = _C.export("ranges", args, False, out[0], out[3:7], H, W, th.int32).cpu().numpy()
+        rows = balanced_bands(row_work_from_ranges(ranges, B, gy, gx), world)[rank]
     del out
 
     sizes = [3 * P, 3 * P, F, B * P, B * F]

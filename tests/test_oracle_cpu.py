@@ -1,0 +1,330 @@
+"""CPU tests of the oracle (no GPU).  The reference has no tests or golden vectors,
+so the oracle is pinned here by
+  * the handful of helper outputs SURVEY.md 8(c) recorded from the reference's own auxiliary.h,
+  * an independent brute-force renderer (no tiling, no binning, no sort; float64 shading),
+  * finite differences for the gradients that are mathematically correct in the reference
+    (not dL_dverts: quirk Q11),
+  * structural properties (watertight top-left rule, band composition, empty inputs).
+"""
+import numpy as np
+import pytest
+import torch as th
+
+from dmesh_renderer_amd import scenes
+from util import upstream_grads
+
+
+# ---------------------------------------------------------------------------
+# helper-level known answers (values recorded in SURVEY.md 8(c))
+# ---------------------------------------------------------------------------
+def test_helper_known_answers(oracle):
+    L = oracle.lib()
+    assert L.dmro_in_tri(10.5, 10.5, 2, 3, 40, 5, 8, 50) == 1
+    o = np.array([0, 0, 3], np.float32); d = np.array([0, 0, -1], np.float32)
+    p0 = np.array([-1, -1, 0], np.float32); p1 = np.array([1, -1, 0], np.float32); p2 = np.array([0, 1, 0], np.float32)
+    tuv = np.zeros(3, np.float32)
+    assert L.dmro_ray_tri(o.ctypes.data, d.ctypes.data, p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, 0, tuv.ctypes.data) == 1
+    np.testing.assert_allclose(tuv, [3.0, 0.25, 0.5], rtol=0, atol=1e-7)
+    import ctypes as C
+    uc, vc, code = C.c_float(), C.c_float(), C.c_int()
+    L.dmro_clamp_bary_uv(1.2, 0.3, C.byref(uc), C.byref(vc), C.byref(code))
+    assert abs(uc.value - 0.95) < 1e-6 and abs(vc.value - 0.05) < 1e-6 and code.value == 6
+    assert L.dmro_ndc2pix(0.1, 1920) == np.float32(1055.5)
+    assert abs(L.dmro_pix2ndc(10.5, 1080) - (-0.979629636)) < 1e-7
+
+
+def test_clamp_regions(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    cases = {(0.2, 0.3): (0.2, 0.3, 0), (-1, -1): (0, 0, 1), (2, -1): (1, 0, 2), (-1, 2): (0, 1, 3),
+             (-0.5, 0.5): (0, 0.5, 4), (0.5, -0.5): (0.5, 0, 5), (0.8, 0.8): (0.5, 0.5, 6), (1.5, 0.2): (1, 0, 2)}
+    for (u, v), (eu, ev, ec) in cases.items():
+        uc, vc, code = C.c_float(), C.c_float(), C.c_int()
+        L.dmro_clamp_bary_uv(u, v, C.byref(uc), C.byref(vc), C.byref(code))
+        assert (abs(uc.value - eu) < 1e-6 and abs(vc.value - ev) < 1e-6 and code.value == ec), (u, v)
+
+
+def test_higher_msb_and_rect(oracle):
+    L = oracle.lib()
+    # rasterizer_impl.cu:25-40: floor(log2(n)) + 1
+    for n in (1, 2, 3, 255, 256, 2500, 8160, 262144):
+        assert L.dmro_higher_msb(n) == int(np.floor(np.log2(n))) + 1
+    rect = np.zeros(4, np.uint32)
+    f = lambda a: np.array(a, np.float32)
+    p0, p1, p2 = f([5, 5]), f([40, 20]), f([20, 60])
+    L.dmro_rect_from_tri(p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, 16, 16, rect.ctypes.data)
+    assert rect.tolist() == [0, 0, 3, 4]
+    # Q4: truncation toward zero maps slightly negative coordinates to tile 0; max side is trunc + 1, clamped
+    p0, p1, p2 = f([-8, -3]), f([300, 10]), f([10, 1000])
+    L.dmro_rect_from_tri(p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, 16, 16, rect.ctypes.data)
+    assert rect.tolist() == [0, 0, 16, 16]
+    # entirely left of the image: empty rect
+    p0, p1, p2 = f([-100, 5]), f([-50, 5]), f([-70, 30])
+    L.dmro_rect_from_tri(p0.ctypes.data, p1.ctypes.data, p2.ctypes.data, 16, 16, rect.ctypes.data)
+    assert (rect[2] - rect[0]) * (rect[3] - rect[1]) in (0, 2)  # trunc(-3.1)=-3 -> clamp 0; max -> trunc+1 = -2 -> 0
+
+
+def test_in_tri_watertight_and_winding(oracle):
+    """Two triangles sharing an edge cover every pixel centre of their union exactly once (top-left
+    rule), whatever the vertex order (auxiliary.h:203-212 swaps to CCW)."""
+    L = oracle.lib()
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        q = (rng.rand(4, 2) * 24 + 2).astype(np.float32)  # quad a,b,c,d split along a-c
+        a, b, c, d = q
+        cross = lambda u, v, w: (v[0] - u[0]) * (w[1] - u[1]) - (w[0] - u[0]) * (v[1] - u[1])
+        if cross(a, c, b) * cross(a, c, d) >= 0:  # b and d must lie on opposite sides of a-c
+            continue
+        for py in range(28):
+            for px in range(28):
+                x, y = px + 0.5, py + 0.5
+                n1 = L.dmro_in_tri(x, y, *a, *b, *c)
+                n2 = L.dmro_in_tri(x, y, *a, *c, *d)
+                assert n1 + n2 <= 1
+                assert n1 == L.dmro_in_tri(x, y, *c, *b, *a)  # winding agnostic
+    assert L.dmro_in_tri(1.5, 1.5, 0, 0, 4, 4, 8, 8) == 0  # zero area
+
+
+# ---------------------------------------------------------------------------
+# brute force: no tiles, no binning, no radix sort; shading in float64
+# ---------------------------------------------------------------------------
+def _in_tri_py(px, py, p1, p2, p3):
+    I = lambda v: int(np.float32(v) * np.float32(16.0))  # truncation toward zero (values are small)
+    x, y = I(px), I(py)
+    x1, y1, x2, y2, x3, y3 = I(p1[0]), I(p1[1]), I(p2[0]), I(p2[1]), I(p3[0]), I(p3[1])
+    area = (x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1)
+    if area == 0:
+        return False
+    if area < 0:
+        x2, y2, x3, y3 = x3, y3, x2, y2
+    ok = True
+    for (ax, ay, bx, by) in ((x1, y1, x2, y2), (x2, y2, x3, y3), (x3, y3, x1, y1)):
+        cx, cy = ax - bx, ay - by
+        s = cx * (y - ay) - cy * (x - ax)
+        if cy > 0 or (cy == 0 and cx > 0):
+            s -= 1
+        ok = ok and s < 0
+    return ok
+
+
+def _clamp_py(u, v):
+    if u >= 0 and v >= 0 and u + v <= 1: return u, v
+    if u <= 0 and v <= 0: return 0.0, 0.0
+    if (u >= 1 and v <= 0) or (v >= 0 and v <= u - 1): return 1.0, 0.0
+    if (u <= 0 and v >= 1) or (u >= 0 and v >= u + 1): return 0.0, 1.0
+    if u <= 0 and 0 <= v <= 1: return 0.0, v
+    if 0 <= u <= 1 and v <= 0: return u, 0.0
+    return (1 + u - v) * 0.5, (1 - u + v) * 0.5
+
+
+def _brute_tri(sc, st):
+    """Per pixel: every face sorted by (depth key bits, face id), composited front to back."""
+    B, P, F, H, W = sc.B, sc.P, sc.F, sc.H, sc.W
+    image = st.get("image").reshape(B, P, 2)
+    depths = st.get("depths").reshape(B, F)
+    touched = st.get("tiles_touched").reshape(B, F) > 0
+    ray_o = st.get("ray_o").reshape(B, H, W, 3).astype(np.float64)
+    ray_d = st.get("ray_d").reshape(B, H, W, 3).astype(np.float64)
+    color = np.zeros((B, 3, H, W)); depth = np.zeros((B, 1, H, W))
+    V = sc.verts.astype(np.float64); C = sc.verts_color.astype(np.float64)
+    for b in range(B):
+        order = sorted([f for f in range(F) if touched[b, f]], key=lambda f: (depths[b, f].view(np.uint32), f))
+        for y in range(H):
+            for x in range(W):
+                T, col, dep = 1.0, np.zeros(3), 0.0
+                o, d = ray_o[b, y, x], ray_d[b, y, x]
+                for f in order:
+                    v = sc.faces[f]
+                    if not _in_tri_py(x + 0.5, y + 0.5, image[b, v[0]], image[b, v[1]], image[b, v[2]]):
+                        continue
+                    p0, p1, p2 = V[v[0]], V[v[1]], V[v[2]]
+                    E1, E2, Tv = p1 - p0, p2 - p0, o - p0
+                    Pv, Q = np.cross(d, E2), np.cross(Tv, E1)
+                    den = Pv @ E1
+                    if den == 0: continue
+                    u, w_ = (Pv @ Tv) / den, (Q @ d) / den
+                    uc, vc = _clamp_py(u, w_)
+                    i0, i1, i2 = 1 - uc - vc, uc, vc
+                    c = (i0 * C[v[0]] + i1 * C[v[1]] + i2 * C[v[2]]) * sc.faces_intense[b, f]
+                    dd = i0 * sc.verts_depth[b, v[0]] + i1 * sc.verts_depth[b, v[1]] + i2 * sc.verts_depth[b, v[2]]
+                    a = float(sc.faces_opacity[f])
+                    col += c * a * T; dep += dd * a * T
+                    T = np.float32(np.float32(T) * np.float32(1 - np.float32(a)))  # the T chain decides early-out
+                    if T < np.float32(1e-4): break
+                color[b, :, y, x] = col + T * sc.bg
+                depth[b, 0, y, x] = dep + T
+    return color, depth
+
+
+@pytest.mark.parametrize("opacity", [(0.1, 0.5), (0.7, 0.99)])
+def test_tri_forward_matches_brute_force(oracle, opacity):
+    H, W = 40, 56
+    d = scenes.layered_sheets(3, 5, 2, H, W, seed=2, opacity=opacity)
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    color, depth, st = oracle.tri_forward(sc)
+    bcolor, bdepth = _brute_tri(sc, st)
+    assert np.abs(color - bcolor).max() < 2e-5
+    assert np.abs(depth - bdepth).max() < 2e-5
+    # sorted list invariants (Q6): keys ascending; within equal keys ascending face id; ranges tile the list
+    keys, vals = st.get("keys"), st.get("values")
+    assert np.all(np.diff(keys.astype(np.int64) >> 32) >= 0)
+    same = keys[1:] == keys[:-1]
+    assert np.all(vals[1:][same] > vals[:-1][same])
+    r = st.get("ranges").reshape(-1, 2)
+    nz = r[r[:, 1] > r[:, 0]]
+    assert nz[0, 0] == 0 and nz[-1, 1] == st.num_rendered and np.all(nz[1:, 0] == nz[:-1, 1])
+    assert st.num_rendered == int(st.get("tiles_touched").sum())
+
+
+def _loss(oracle, d, H, W, gc, gd):
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    color, depth, st = oracle.tri_forward(sc)
+    return float((color.astype(np.float64) * gc.numpy()).sum() + (depth.astype(np.float64) * gd.numpy()).sum())
+
+
+def test_tri_backward_finite_differences(oracle):
+    """dL/d{verts_color, faces_opacity, verts_depth, faces_intense}: the image is linear / smooth in
+    these, coverage does not depend on them, so central differences are exact up to fp32 noise."""
+    H, W = 48, 48
+    d = scenes.layered_sheets(3, 6, 1, H, W, seed=5, opacity=(0.2, 0.6))
+    gc, gd = upstream_grads(1, H, W)
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    _, _, st = oracle.tri_forward(sc)
+    g = oracle.tri_backward(sc, st, gc.numpy(), gd.numpy())
+    rng = np.random.RandomState(0)
+    eps = 1e-2
+    for key in ("verts_color", "faces_opacity", "verts_depth", "faces_intense"):
+        flat = d[key].reshape(-1)
+        big = np.argsort(-np.abs(g[key].reshape(-1)))[:3]
+        for idx in list(big) + list(rng.choice(flat.numel(), 3, replace=False)):
+            dp = {k: v.clone() for k, v in d.items()}; dm = {k: v.clone() for k, v in d.items()}
+            dp[key].reshape(-1)[idx] += eps; dm[key].reshape(-1)[idx] -= eps
+            fd = (_loss(oracle, dp, H, W, gc, gd) - _loss(oracle, dm, H, W, gc, gd)) / (2 * eps)
+            an = float(g[key].reshape(-1)[idx])
+            assert abs(fd - an) <= 2e-3 * max(1.0, abs(an)), (key, int(idx), fd, an)
+
+
+def test_tri_bands_compose(oracle):
+    H, W = 72, 88
+    d = scenes.layered_sheets(3, 7, 2, H, W, seed=1)
+    gc, gd = upstream_grads(2, H, W)
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    color, depth, st = oracle.tri_forward(sc)
+    g = oracle.tri_backward(sc, st, gc.numpy(), gd.numpy())
+    csum = np.zeros_like(color); gsum = {k: np.zeros_like(v) for k, v in g.items()}
+    R = 0
+    for rows in ((0, 2), (2, 3), (3, 5)):
+        scb = oracle.scene_from_module_inputs(d, H, W, rows=rows)
+        cb, db, stb = oracle.tri_forward(scb)
+        csum += cb; R += stb.num_rendered
+        gb = oracle.tri_backward(scb, stb, gc.numpy(), gd.numpy())
+        for k in g: gsum[k] += gb[k]
+    assert np.array_equal(csum, color) and R == st.num_rendered
+    for k in g:
+        assert np.abs(gsum[k] - g[k]).max() <= 1e-5 * max(1.0, np.abs(g[k]).max())
+
+
+def test_tri_empty_and_culled(oracle):
+    H = W = 32
+    d = scenes.layered_sheets(1, 3, 1, H, W)
+    for P, F in ((0, 0), (9, 0)):
+        dd = dict(d)
+        dd["verts"], dd["verts_color"], dd["verts_depth"] = d["verts"][:P], d["verts_color"][:P], d["verts_depth"][:, :P]
+        dd["faces"], dd["faces_opacity"], dd["faces_intense"] = d["faces"][:F], d["faces_opacity"][:F], d["faces_intense"][:, :F]
+        sc = oracle.scene_from_module_inputs(dd, H, W)
+        color, depth, st = oracle.tri_forward(sc)
+        assert st.num_rendered == 0 and not color.any() and not depth.any()  # render.cu:104-105
+    # everything behind the far plane / off-screen: culled, background + depth 1 everywhere
+    dd = dict(d); dd["verts"] = d["verts"] + th.tensor([0.0, 0.0, -50.0])
+    sc = oracle.scene_from_module_inputs(dd, H, W)
+    color, depth, st = oracle.tri_forward(sc)
+    assert st.num_rendered == 0 and np.all(depth == 1.0) and not color.any()
+
+
+# ---------------------------------------------------------------------------
+# tet renderer
+# ---------------------------------------------------------------------------
+def test_tet_march_matches_sorted_intersections(oracle):
+    """For active pixels the march must visit exactly the faces the ray really intersects, in order of
+    the ray parameter t (that is the point of the tet renderer, README.md:4)."""
+    H = W = 48
+    d = scenes.kuhn_tets(3, 1, H, W, seed=0, opacity=(0.05, 0.3))
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    color, depth, active, st = oracle.tet_forward(sc)
+    assert active.mean() > 0.3
+    ray_o = st.get("ray_o").reshape(H, W, 3).astype(np.float64)
+    ray_d = st.get("ray_d").reshape(H, W, 3).astype(np.float64)
+    V = sc.verts.astype(np.float64); C = sc.verts_color.astype(np.float64)
+    ncon = st.get("n_contrib").reshape(H, W)
+    checked = 0
+    for y in range(0, H, 3):
+        for x in range(0, W, 3):
+            if active[0, y, x] < 0.5:
+                continue
+            o, dr = ray_o[y, x], ray_d[y, x]
+            hits = []
+            for f in range(sc.F):
+                p0, p1, p2 = V[sc.faces[f, 0]], V[sc.faces[f, 1]], V[sc.faces[f, 2]]
+                E1, E2, Tv = p1 - p0, p2 - p0, o - p0
+                Pv, Q = np.cross(dr, E2), np.cross(Tv, E1)
+                den = Pv @ E1
+                if abs(den) < 1e-12: continue
+                t, u, v = (Q @ E2) / den, (Pv @ Tv) / den, (Q @ dr) / den
+                if t >= 0 and u >= 1e-6 and v >= 1e-6 and u + v <= 1 - 1e-6:  # strictly inside: unambiguous
+                    hits.append((t, f, u, v))
+            hits.sort()
+            if len(hits) != ncon[y, x]:
+                continue  # ray grazes an edge somewhere: the brute force is ambiguous there, skip
+            T, col = 1.0, np.zeros(3)
+            for t, f, u, v in hits:
+                c0, c1, c2 = C[sc.faces[f, 0]], C[sc.faces[f, 1]], C[sc.faces[f, 2]]
+                c = (c0 + (c1 - c0) * u + (c2 - c0) * v) * sc.faces_intense[0, f]
+                a = float(sc.faces_opacity[f])
+                col += T * a * c
+                T *= (1 - a)
+            np.testing.assert_allclose(color[0, :, y, x], col + T * sc.bg, atol=3e-5)
+            checked += 1
+    assert checked > 20
+
+
+def test_tet_backward_finite_differences(oracle):
+    H = W = 40
+    d = scenes.kuhn_tets(3, 1, H, W, seed=1, opacity=(0.1, 0.5))
+    gc, gd = upstream_grads(1, H, W)
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    _, _, _, st = oracle.tet_forward(sc)
+    g = oracle.tet_backward(sc, st, gc.numpy(), gd.numpy())
+
+    def loss(dd):
+        s2 = oracle.scene_from_module_inputs(dd, H, W)
+        c, dp, _, _ = oracle.tet_forward(s2)
+        return float((c.astype(np.float64) * gc.numpy()).sum() + (dp.astype(np.float64) * gd.numpy()).sum())
+
+    eps = 1e-2
+    for key in ("verts_color", "faces_opacity"):
+        big = np.argsort(-np.abs(g[key].reshape(-1)))[:4]
+        for idx in big:
+            dp = {k: v.clone() for k, v in d.items()}; dm = {k: v.clone() for k, v in d.items()}
+            dp[key].reshape(-1)[idx] += eps; dm[key].reshape(-1)[idx] -= eps
+            fd = (loss(dp) - loss(dm)) / (2 * eps)
+            an = float(g[key].reshape(-1)[idx])
+            assert abs(fd - an) <= 5e-3 * max(1.0, abs(an)), (key, int(idx), fd, an)
+
+
+def test_tet_topology_of_scene():
+    d = scenes.kuhn_tets(3, 1, 32, 32)
+    T, F = d["tets"].shape[0], d["faces"].shape[0]
+    assert T == 6 * 27 and F == 12 * 27 + 6 * 9
+    ft, tf = d["face_tets"].numpy(), d["tet_faces"].numpy()
+    assert ((ft[:, 1] == -1).sum()) == 2 * 6 * 9  # boundary faces: 2 triangles per boundary quad
+    for t in range(0, T, 7):
+        for f in tf[t]:
+            assert t in ft[f]
+            assert set(d["faces"][f].tolist()) <= set(d["tets"][t].tolist())
+
+
+def test_tet_seed_rejected(oracle):
+    d = scenes.kuhn_tets(2, 1, 32, 32)
+    sc = oracle.scene_from_module_inputs(d, 32, 32, seed=3)
+    with pytest.raises(RuntimeError, match="parity-unpinned"):
+        oracle.tet_forward(sc)
