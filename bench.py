@@ -26,6 +26,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# host threads of the cpu_baseline leg: the 1-GPU share of the box (16), set before any OpenMP runtime loads
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
 import numpy as np
 import torch as th
