@@ -265,16 +265,19 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 constexpr int NACC = 23;  // 9 dverts, 9 dvcolor, 3 dvdepth, dopacity, dintense
 constexpr int BWD_SLOTS = 8;
 
-// DPP lane moves (VALU, no LDS traffic).  A lane whose source is outside its 16-lane row (row_shr)
-// or outside the written rows (row_bcast, row_mask) keeps `old`.
+// DPP lane moves (VALU, no LDS traffic).  dpp_i: a lane whose source is outside its 16-lane row
+// (row_shr) or outside the written rows (row_bcast, row_mask) keeps `old`.  dpp_f_any: same move, but the
+// value of such lanes is unspecified (callers ignore it) -- no register initialisation, no hazard nops.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
 }
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float old, float src) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
+__device__ __forceinline__ float dpp_f_any(float src) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), CTRL, ROW_MASK, 0xF, true));
 }
+// 1-ulp reciprocal (v_rcp_f32): gradients are checked to 1e-4, the forward keeps IEEE division
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 constexpr int DPP_ROW_SHR = 0x110;      // + n, n = 1..15
 constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of the next row
 constexpr int DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
@@ -287,7 +290,7 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
     const bool same = (ko == k);
 #pragma unroll
     for (int c = 0; c < NACC; c++) {
-        const float o = dpp_f<CTRL, ROW_MASK>(0.f, g[c]);
+        const float o = dpp_f_any<CTRL, ROW_MASK>(g[c]);
         g[c] += same ? o : 0.f;
     }
 }
@@ -416,7 +419,7 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
                 const V3 Pv = cross(rd, E2);
                 const float denom = dot(Pv, E1);
                 if (denom == 0.0f) continue;  // "edge case": skipped entirely (backward.cu:215-216)
-                const float inv_denom = 1.0f / denom;
+                const float inv_denom = fast_rcp(denom);
                 const float iu = dot(Pv, Tv) * inv_denom;
                 const float iv = dot(Q, rd) * inv_denom;
                 float iuc, ivc; int code;
@@ -428,7 +431,8 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
                 const float iC2 = (i0 * r.c0[2] + i1 * r.c1[2] + i2 * r.c2[2]) * intense;
                 const float iD = i0 * r.d0 + i1 * r.d1 + i2 * r.d2;
                 const float alpha = r.opacity;
-                if (!first_pass) T = T / (1.f - alpha);  // Q10
+                const float inv_1ma = fast_rcp(1.f - alpha);
+                if (!first_pass) T = T * inv_1ma;  // Q10
                 first_pass = false;
                 float dL_dalpha = 0.0f;
                 acr0 = last_alpha * lc0 + (1.f - last_alpha) * acr0; lc0 = iC0; dL_dalpha += (iC0 - acr0) * dpc0;
@@ -442,8 +446,8 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
                     dL_dalpha += (-prev_T_final) * bg_dot;
                     dL_dalpha += (-prev_T_final) * bd_dot;
                 } else {
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bd_dot;
+                    dL_dalpha += (-T_final * inv_1ma) * bg_dot;
+                    dL_dalpha += (-T_final * inv_1ma) * bd_dot;
                 }
                 s_pool[h][tid] = make_float2(T, dL_dalpha);
                 pm |= bit;
@@ -523,7 +527,7 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
 
                     const V3 Pv = cross(d, E2);
                     const float denom = dot(Pv, E1);
-                    const float inv_denom = 1.0f / denom;
+                    const float inv_denom = fast_rcp(denom);
                     const float nu = dot(Pv, Tv);
                     const float iu = nu * inv_denom;
                     const float iv = dot(Q, d) * inv_denom;
@@ -551,7 +555,7 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
                     const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
 
                     // ray_tri_intersection_grad (auxiliary.h:288-333), Q11/Q12 kept
-                    const float dsq = denom, den2 = dsq * dsq, dinv = 1.0f / den2;
+                    const float dsq = denom, den2 = dsq * dsq, dinv = fast_rcp(den2);
                     const float v0 = nu, v1 = dsq, v2 = dot(Q, E2);
                     const V3 du_dE1 = (-1.0f * Pv * v0) * dinv;
                     const V3 du_dE2 = (cross(Tv, d) * v1 - v0 * cross(E1, d)) * dinv;
