@@ -54,10 +54,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    # DMR_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the sharded path on a 1-GPU box;
+    # the driver's multi-GPU runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("DMR_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(1, th.cuda.device_count()) if backend != "nccl" else local_rank
     th.cuda.set_device(local_rank)
     dev = th.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     n_gpus = world
 
     from dmesh_renderer_amd import _C, _lib, scenes

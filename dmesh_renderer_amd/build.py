@@ -40,6 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB + ".tmp"]
+    cmd += os.environ.get("DMR_HIPCC_FLAGS", "").split()  # tuning experiments only
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -28,19 +28,26 @@
 
 namespace dmr {
 
+#ifndef DMR_COV_UNROLL
+#define DMR_COV_UNROLL 4
+#endif
 constexpr int FWD_CHUNK = 128;
 constexpr int BWD_CHUNK = 64;
 
 // s_i(x, y) = s0[i] + bx[i] * (x - x0) + by[i] * (y - y0) (mod 2^32), inside iff all three < 0.
 // A zero-area face (in_tri returns false, auxiliary.h:201-202) and the padding entries of a
 // partially filled 32-face word are stored as the all-zero record, which covers nothing.
-// `big` != 0: some bx/by does not fit a signed 24-bit operand (an edge longer than 32768 px), so the
-// chunk must use full 32-bit multiplies instead of v_mad_i32_i24.
+// flags bit 8 (COV_BIG): some bx/by does not fit a signed 24-bit operand (an edge longer than 32768 px),
+// so the chunk must use full 32-bit multiplies instead of v_mad_i32_i24.
+// flags bits 0-3: which 8x8 quadrants of the tile the face's fixed-point bounding box can cover at all
+// (bit q = quadrant (q & 1, q >> 1)); 15 whenever the face is not "near" the tile, i.e. when int32
+// wrap-around (Q7) could make the edge functions claim pixels outside the box.
 struct alignas(16) CovRec {
-    int32_t s0[3]; int32_t big;
+    int32_t s0[3]; int32_t flags;
     int32_t bx[3]; int32_t pad0;
     int32_t by[3]; int32_t pad1;
 };
+constexpr int COV_BIG = 0x100;
 static_assert(sizeof(CovRec) == 48, "CovRec");
 
 // T = ray_o - p0, E1 = p1 - p0, E2 = p2 - p0, Q = cross(T, E1): the pixel-independent part of
@@ -77,7 +84,7 @@ __device__ __forceinline__ int stage_face(const TriParams& p, int b, int face, i
         cov.s0[i] = e.ok ? e.s0[i] : 0; cov.bx[i] = e.ok ? e.bx[i] : 0; cov.by[i] = e.ok ? e.by[i] : 0;
         big |= (cov.bx[i] != ((cov.bx[i] << 8) >> 8)) | (cov.by[i] != ((cov.by[i] << 8) >> 8));
     }
-    cov.big = big; cov.pad0 = 0; cov.pad1 = 0;
+    cov.flags = e.ok ? ((big ? COV_BIG : 0) | e.qmask) : 0; cov.pad0 = 0; cov.pad1 = 0;
     const V3 T = ray_o - p0, E1 = p1 - p0, E2 = p2 - p0;
     const V3 Q = cross(T, E1);
     sh.T[0] = T.x; sh.T[1] = T.y; sh.T[2] = T.z;
@@ -110,34 +117,47 @@ template <bool BIG, int NB>
 __device__ __forceinline__ void coverage_block(const CovRec* __restrict__ cov, int count, int lane, uint32_t mq[4]) {
     const int lx = lane & 7, ly = lane >> 3;
     mq[0] = mq[1] = mq[2] = mq[3] = 0;
-    const int rounds = (count + 3) >> 2;  // records beyond `count` inside the last group of 4 are null records
-    for (int j4 = 0; j4 < rounds; j4++) {
+    if (count <= 0) return;
+    // software pipeline: the record of face j+1 is in flight while face j is evaluated
+    const int4* __restrict__ q = reinterpret_cast<const int4*>(cov);
+    int4 n0 = q[0], n1 = q[1], n2 = q[2];
+    for (int j = 0; j < count; j++) {
+        const int4 c0 = n0, c1 = n1, c2 = n2;  // {s0[3], flags}, {bx[3], -}, {by[3], -}
+        const int jn = min(j + 1, count - 1);
+        n0 = q[3 * jn]; n1 = q[3 * jn + 1]; n2 = q[3 * jn + 2];
+        // wave-uniform: quadrants the face's box misses cost one scalar branch instead of ~8 VALU
+        const int qm = __builtin_amdgcn_readfirstlane(c0.w) & 15;
+        if (qm == 0) continue;
+        const int s0[3] = {c0.x, c0.y, c0.z}, bx[3] = {c1.x, c1.y, c1.z}, by[3] = {c2.x, c2.y, c2.z};
+        uint32_t e[3];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = 4 * j4 + u;
-            const CovRec& c = cov[j];
-            uint32_t e[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                if (BIG) e[i] = (uint32_t)c.s0[i] + (uint32_t)c.bx[i] * (uint32_t)lx + (uint32_t)c.by[i] * (uint32_t)ly;
-                else e[i] = (uint32_t)(__mul24(c.by[i], ly) + (__mul24(c.bx[i], lx) + c.s0[i]));
-            }
-            const uint32_t bit = 1u << j;
-            uint32_t t0 = e[0] & e[1] & e[2];
-            uint32_t t1 = (e[0] + ((uint32_t)c.bx[0] << 3)) & (e[1] + ((uint32_t)c.bx[1] << 3)) & (e[2] + ((uint32_t)c.bx[2] << 3));
-            uint32_t t2 = (e[0] + ((uint32_t)c.by[0] << 3)) & (e[1] + ((uint32_t)c.by[1] << 3)) & (e[2] + ((uint32_t)c.by[2] << 3));
-            uint32_t t3 = (e[0] + ((uint32_t)c.bx[0] << 3) + ((uint32_t)c.by[0] << 3)) & (e[1] + ((uint32_t)c.bx[1] << 3) + ((uint32_t)c.by[1] << 3))
-                        & (e[2] + ((uint32_t)c.bx[2] << 3) + ((uint32_t)c.by[2] << 3));
-            mq[0] |= ((int32_t)t0 < 0) ? bit : 0u;
-            mq[1] |= ((int32_t)t1 < 0) ? bit : 0u;
-            mq[2] |= ((int32_t)t2 < 0) ? bit : 0u;
-            mq[3] |= ((int32_t)t3 < 0) ? bit : 0u;
+        for (int i = 0; i < 3; i++) {
+            if (BIG) e[i] = (uint32_t)s0[i] + (uint32_t)bx[i] * (uint32_t)lx + (uint32_t)by[i] * (uint32_t)ly;
+            else e[i] = (uint32_t)(__mul24(by[i], ly) + (__mul24(bx[i], lx) + s0[i]));
+        }
+        const uint32_t bit = 1u << j;
+        if (qm & 1) {
+            const uint32_t t = e[0] & e[1] & e[2];
+            mq[0] |= (uint32_t)((int32_t)t >> 31) & bit;
+        }
+        if (qm & 2) {
+            const uint32_t t = (e[0] + ((uint32_t)bx[0] << 3)) & (e[1] + ((uint32_t)bx[1] << 3)) & (e[2] + ((uint32_t)bx[2] << 3));
+            mq[1] |= (uint32_t)((int32_t)t >> 31) & bit;
+        }
+        if (qm & 4) {
+            const uint32_t t = (e[0] + ((uint32_t)by[0] << 3)) & (e[1] + ((uint32_t)by[1] << 3)) & (e[2] + ((uint32_t)by[2] << 3));
+            mq[2] |= (uint32_t)((int32_t)t >> 31) & bit;
+        }
+        if (qm & 8) {
+            const uint32_t t = (e[0] + ((uint32_t)bx[0] << 3) + ((uint32_t)by[0] << 3)) & (e[1] + ((uint32_t)bx[1] << 3) + ((uint32_t)by[1] << 3))
+                             & (e[2] + ((uint32_t)bx[2] << 3) + ((uint32_t)by[2] << 3));
+            mq[3] |= (uint32_t)((int32_t)t >> 31) & bit;
         }
     }
 }
 
 template <int CHUNK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ out_depth) {
     constexpr int WORDS = CHUNK / 32;
     static_assert(WORDS == 4, "one 32-face block per wave");
@@ -282,17 +302,40 @@ constexpr int DPP_ROW_SHR = 0x110;      // + n, n = 1..15
 constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of the next row
 constexpr int DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
 
-// one level of the segmented inclusive scan over the 23 components: lanes whose source lane carries the
-// same face key add the source's partial sum
+// One level of the segmented inclusive scan over the 23 components: lanes whose source lane carries the
+// same face key add the source's partial sum.  Hand-scheduled: hipcc turns the obvious
+// "g += same ? dpp(g) : 0" into mov + nop + mov_dpp + cndmask + add per value; here it is
+// v_cndmask_b32_dpp (select 0 / shifted value on VCC = "different key") + v_add_f32 -- two VALU per value.
+// Lanes without a valid source read 0 (bound_ctrl:0); rows excluded by row_mask never write `t`, which
+// is zeroed once per level.
+#define DMR_SEG2(N, DPP) "v_cndmask_b32_dpp %[t], %[g" #N "], %[z], vcc " DPP "\n\tv_add_f32 %[g" #N "], %[g" #N "], %[t]\n\t"
+#define DMR_SEG_LEVEL(DPP)                                                                                     \
+    asm volatile("s_mov_b64 vcc, %[ns]\n\tv_mov_b32 %[t], 0\n\ts_nop 1\n\t"                                     \
+                 DMR_SEG2(0, DPP) DMR_SEG2(1, DPP) DMR_SEG2(2, DPP) DMR_SEG2(3, DPP) DMR_SEG2(4, DPP) DMR_SEG2(5, DPP)  \
+                 DMR_SEG2(6, DPP) DMR_SEG2(7, DPP) DMR_SEG2(8, DPP) DMR_SEG2(9, DPP) DMR_SEG2(10, DPP) DMR_SEG2(11, DPP) \
+                 DMR_SEG2(12, DPP) DMR_SEG2(13, DPP) DMR_SEG2(14, DPP) DMR_SEG2(15, DPP) DMR_SEG2(16, DPP)          \
+                 DMR_SEG2(17, DPP) DMR_SEG2(18, DPP) DMR_SEG2(19, DPP) DMR_SEG2(20, DPP) DMR_SEG2(21, DPP)          \
+                 DMR_SEG2(22, DPP)                                                                             \
+                 : [t] "=&v"(t), [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]),  \
+                   [g5] "+v"(g[5]), [g6] "+v"(g[6]), [g7] "+v"(g[7]), [g8] "+v"(g[8]), [g9] "+v"(g[9]),             \
+                   [g10] "+v"(g[10]), [g11] "+v"(g[11]), [g12] "+v"(g[12]), [g13] "+v"(g[13]), [g14] "+v"(g[14]),   \
+                   [g15] "+v"(g[15]), [g16] "+v"(g[16]), [g17] "+v"(g[17]), [g18] "+v"(g[18]), [g19] "+v"(g[19]),   \
+                   [g20] "+v"(g[20]), [g21] "+v"(g[21]), [g22] "+v"(g[22])                                      \
+                 : [z] "v"(0.0f), [ns] "s"(ns)                                                                 \
+                 : "vcc")
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
+    static_assert(NACC == 23, "the asm lists 23 registers");
     const int ko = dpp_i<CTRL, ROW_MASK>((int)0x80000000, k);
-    const bool same = (ko == k);
-#pragma unroll
-    for (int c = 0; c < NACC; c++) {
-        const float o = dpp_f_any<CTRL, ROW_MASK>(g[c]);
-        g[c] += same ? o : 0.f;
-    }
+    const uint64_t ns = __ballot(ko != k);  // lanes that must NOT add (different face, or no source lane)
+    float t;
+    if (CTRL == DPP_ROW_SHR + 1) DMR_SEG_LEVEL("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    else if (CTRL == DPP_ROW_SHR + 2) DMR_SEG_LEVEL("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    else if (CTRL == DPP_ROW_SHR + 4) DMR_SEG_LEVEL("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    else if (CTRL == DPP_ROW_SHR + 8) DMR_SEG_LEVEL("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    else if (CTRL == DPP_ROW_BCAST15) DMR_SEG_LEVEL("row_bcast:15 row_mask:0xa bank_mask:0xf bound_ctrl:0");
+    else DMR_SEG_LEVEL("row_bcast:31 row_mask:0xc bank_mask:0xf bound_ctrl:0");
 }
 
 __global__ void __launch_bounds__(256, 3)

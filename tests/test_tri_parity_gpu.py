@@ -21,7 +21,18 @@ CASES = {
     "C1_opaque": (4, 17, 1, 256, 256, (0.5, 0.95)),         # exercises early termination (T < 1e-4)
     "ragged": (3, 12, 2, 200, 328, (0.1, 0.6)),             # W, H not multiples of 16; two views
     "dense": (12, 9, 1, 64, 64, (0.05, 0.3)),               # long tile lists: several LDS chunks per tile
+    # triangles far larger than the image, vertices far off-screen and behind the camera (mirrored by
+    # clamp_w, Q2): exercises whole-tile coverage, the non-"near" / 32-bit coverage paths and int32 wrap (Q7)
+    "huge": (3, 4, 2, 96, 144, (0.1, 0.4)),
 }
+
+
+def _make(case):
+    L, n, B, H, W, op = CASES[case]
+    d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
+    if case == "huge":
+        d["verts"] = d["verts"] * th.tensor([40.0, 40.0, 3.0])
+    return d, B, H, W
 
 
 def _run(oracle, dev, d, H, W, rows=(0, 0)):
@@ -37,8 +48,7 @@ def _run(oracle, dev, d, H, W, rows=(0, 0)):
 @pytest.mark.parametrize("case", list(CASES))
 def test_forward_and_indices(oracle, hip_device, case):
     from dmesh_renderer_amd import _C
-    L, n, B, H, W, op = CASES[case]
-    d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
+    d, B, H, W = _make(case)
     sc, (ocolor, odepth, ost), args, out = _run(oracle, hip_device, d, H, W)
     R, color, depth, bufs = out[0], out[1], out[2], out[3:7]
     assert R == ost.num_rendered
@@ -68,8 +78,7 @@ def test_forward_and_indices(oracle, hip_device, case):
 @pytest.mark.parametrize("case", list(CASES))
 def test_backward(oracle, hip_device, case):
     from dmesh_renderer_amd import _C
-    L, n, B, H, W, op = CASES[case]
-    d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
+    d, B, H, W = _make(case)
     sc, (ocolor, odepth, ost), args, out = _run(oracle, hip_device, d, H, W)
     gc, gd = upstream_grads(B, H, W)
     og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
