@@ -117,8 +117,8 @@ def main():
     for _ in range(a.warmup):
         step()
     # dominant kernels are HIP-event timed INSIDE the timed region (2 events per launch on the launch stream)
-    FWD, BWD = 5, 6
-    lib.dmr_profile_enable((1 << FWD) | (1 << BWD))
+    FWD, BWD1, BWD2 = 5, 6, 11
+    lib.dmr_profile_enable((1 << FWD) | (1 << BWD1) | (1 << BWD2))
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -135,18 +135,20 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = B * W * H * a.steps / dt / 1e6
 
-    # roofline of the dominant kernel.  Algorithmic bytes (rays fused):
-    #   k_tri_forward  : 132 B per list entry (4 B id + 128 B face record) + 28 B per pixel
-    #   k_tri_backward : 132 B per list entry + 184 B per (tile, face) gradient RMW + 28 B per pixel
+    # roofline of the dominant kernel.  Algorithmic bytes per launch (rays fused):
+    #   k_tri_forward       : 132 B per list entry (4 B id + 128 B face record) + 28 B per pixel
+    #   k_tri_backward_pix  : 132 B per list entry + 28 B per pixel (state 12 + dL_dpix 16)
+    #   k_tri_backward_hits : 184 B per list entry (23 fp32 read-modify-writes per (tile, face))
+    # (the hit-record stream between the two backward kernels is this design's own traffic, not algorithmic)
     npix_band = B * W * min(H, (rows[1] - rows[0]) * 16) if world > 1 else B * W * H
-    alg = {FWD: 132.0 * R + 28.0 * npix_band, BWD: 316.0 * R + 28.0 * npix_band}
-    dom = FWD if ms[FWD] >= ms[BWD] else BWD
+    alg = {FWD: 132.0 * R + 28.0 * npix_band, BWD1: 132.0 * R + 28.0 * npix_band, BWD2: 184.0 * R}
+    dom = max((FWD, BWD1, BWD2), key=lambda i: ms[i])
     dom_ms = ms[dom] / max(1, cnt[dom])
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": lib.dmr_stage_name(dom).decode(), "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_ms": round(dom_ms, 4), "algorithmic_bytes": alg[dom],
-                "note": "composite kernels are VALU-bound (256 coverage tests per list entry), see DESIGN.md"}
+                "note": "composite kernels are VALU/latency-bound (256 coverage tests per list entry, ~450 flops per hit), see DESIGN.md"}
 
     # full per-stage table (separate, untimed-for-value pass)
     lib.dmr_profile_enable(0xFFFFFFFF)

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libdmesh_renderer_hip.so")
 ABI_VERSION = 1
 
 BUF_POINT, BUF_FACE, BUF_BINNING, BUF_IMAGE, BUF_WORK = range(5)
-NUM_STAGES = 11
+NUM_STAGES = 12
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 

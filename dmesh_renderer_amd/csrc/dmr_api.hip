@@ -47,6 +47,7 @@ struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* ti
 struct ImageState {
     uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_cursor; int* num_rendered;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
+    uint32_t* tile_hits; uint32_t* hit_offset; unsigned long long* hit_total;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
 };
 struct BinningState { uint64_t* keys; uint32_t* face_list; };
@@ -64,6 +65,8 @@ size_t carve_image(void* b, size_t ntiles, size_t npix, bool tet, ImageState& s)
     s.tile_count = c.take<uint32_t>(ntiles); s.tile_offset = c.take<uint32_t>(ntiles + 1);
     s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(1);
     s.final_T = c.take<float>(npix); s.final_prev_T = c.take<float>(npix); s.n_contrib = c.take<uint32_t>(npix);
+    s.tile_hits = c.take<uint32_t>(ntiles); s.hit_offset = c.take<uint32_t>(ntiles + 1);
+    s.hit_total = c.take<unsigned long long>(1);
     if (tet) {
         s.first_face = c.take<int32_t>(npix); s.first_tet = c.take<int32_t>(npix);
         s.last_face = c.take<int32_t>(npix); s.last_tet = c.take<int32_t>(npix);
@@ -209,8 +212,9 @@ int dmr_profile_collect(double* ms, int64_t* launches) {
 
 const char* dmr_stage_name(int stage) {
     static const char* names[DMR_NUM_STAGES] = {"k_project_verts", "k_setup_faces", "k_scan_tiles", "k_scatter_faces",
-                                                "k_sort_tiles", "k_tri_forward", "k_tri_backward", "k_tri_unpack",
-                                                "k_tet_first_intersect", "k_tet_forward", "k_tet_backward"};
+                                                "k_sort_tiles", "k_tri_forward", "k_tri_backward_pix", "k_tri_unpack",
+                                                "k_tet_first_intersect", "k_tet_forward", "k_tet_backward",
+                                                "k_tri_backward_hits"};
     return (stage >= 0 && stage < DMR_NUM_STAGES) ? names[stage] : "?";
 }
 
@@ -228,7 +232,8 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PointState ps; FaceState fs; ImageState is; BinningState bs;
     if (run_binning(s, false, d, alloc, ctx, st, ps, fs, is, bs, num_rendered)) return 1;
-    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib};
+    DMR_HIP(hipMemsetAsync(is.tile_hits, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
+    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
     dmr::launch_tri_forward(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
                             out_depth, st);
     DMR_HIP(hipGetLastError());
@@ -261,15 +266,28 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     carve_image(const_cast<void*>(image_buf), (size_t)d.ntiles, d.npix, false, is);
     carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, bs);
 
+    // The forward counted the blended (pixel, face) pairs per tile; their scan places every tile's hit
+    // records and the total sizes the record buffer (the backward's one 8-byte host read).
+    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, st);
+    unsigned long long* host_total = reinterpret_cast<unsigned long long*>(pinned_slot());
+    if (!host_total) return fail("hipHostMalloc failed");
+    DMR_HIP(hipMemcpyAsync(host_total, is.hit_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    DMR_HIP(hipStreamSynchronize(st));
+    const unsigned long long nhits = *host_total;
+    if (nhits >= 0xffffffffull) return fail("more than 2^32 blended (pixel, face) pairs");
     const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
-    char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes));
+    const size_t pbytes = up(sizeof(float4) * 2 * d.npix), hbytes = up(sizeof(dmr::HitRecord) * (size_t)nhits);
+    char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes + pbytes + hbytes));
     if (!work) return fail("workspace allocation failed");
     float* vrow = reinterpret_cast<float*>(work);
     float* frow = reinterpret_cast<float*>(work + vbytes);
+    float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
+    dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
     DMR_HIP(hipMemsetAsync(work, 0, vbytes + fbytes, st));
-    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib};
-    dmr::launch_tri_backward(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, dL_dcolor,
-                             dL_ddepth, vrow, frow, st);
+    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
+    dmr::launch_tri_backward_pix(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, dL_dcolor,
+                                 dL_ddepth, pixrec, hits, st);
+    dmr::launch_tri_backward_hits(*s, ps.vproj, bs.face_list, pixrec, hits, (uint32_t)nhits, vrow, frow, st);
     dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
     DMR_HIP(hipGetLastError());
     return 0;

@@ -237,6 +237,31 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
     if (tid == 0) { tile_offset[n] = carry_s; *num_rendered = (int)carry_s; }
 }
 
+// exclusive scan of the per-tile hit counts of the forward (u32 offsets, u64 total)
+__global__ void __launch_bounds__(1024)
+k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, uint32_t* __restrict__ hit_offset,
+            unsigned long long* __restrict__ hit_total) {
+    __shared__ unsigned long long wave_sum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + 1023) / 1024;
+    const int begin = min(n, tid * per), end = min(n, begin + per);
+    unsigned long long local = 0;
+    for (int i = begin; i < end; i++) local += tile_hits[i];
+    unsigned long long incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    unsigned long long base = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) base += wave_sum[w]; total += wave_sum[w]; }
+    unsigned long long run = base + incl - local;
+    for (int i = begin; i < end; i++) { hit_offset[i] = (uint32_t)run; run += tile_hits[i]; }
+    if (tid == 0) { hit_offset[n] = (uint32_t)total; *hit_total = total; }
+}
+
 // ---------------------------------------------------------------------------
 // 4. scatter every (face, tile) pair into its tile's segment: key = depth_bits << 32 | face_id
 // ---------------------------------------------------------------------------
@@ -366,6 +391,12 @@ void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_of
                        int* num_rendered, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
     k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered);
+}
+
+void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
+                      hipStream_t st) {
+    StageScope t(DMR_STAGE_SCAN, st);
+    k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, hit_offset, hit_total);
 }
 
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,

@@ -22,6 +22,7 @@
 // hit's 23 gradient components into per-face LDS accumulators (ds_add_f32), and flushes a
 // chunk with packed atomics: 3 vertex rows + 1 face row per (tile, face) instead of the
 // reference's 23 global atomics per (pixel, face).
+#include <algorithm>
 #include <cstdlib>
 
 #include "dmr_kernels.hpp"
@@ -29,7 +30,7 @@
 namespace dmr {
 
 #ifndef DMR_COV_UNROLL
-#define DMR_COV_UNROLL 4
+#define DMR_COV_UNROLL 1
 #endif
 constexpr int FWD_CHUNK = 128;
 constexpr int BWD_CHUNK = 64;
@@ -66,6 +67,7 @@ struct TriParams {
     const float* inv_mv; const float* inv_proj; const float* faces_intense; const float* bg;
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
+    uint32_t* tile_hits; const uint32_t* hit_offset;
 };
 
 // returns cov.big
@@ -181,7 +183,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
 
     float T = 1.0f, pT = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
-    uint32_t last_contributor = 0;
+    uint32_t last_contributor = 0, n_hits = 0;
     bool done = !inside;
 
     for (uint32_t base = begin; base < end; base += CHUNK) {
@@ -243,10 +245,16 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
             D += iD * alpha * T;
             pT = T; T = test_T;
             last_contributor = (base - begin) + (uint32_t)k + 1u;
+            n_hits++;
             if (T < T_EPS) { done = true; break; }  // blend first, test after (Q9)
         }
     }
 
+    if (begin != end) {  // blended (pixel, face) pairs of the tile: sizes the backward's hit-record buffer
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) n_hits += __shfl_xor(n_hits, dlt, 64);
+        if (lane == 0 && n_hits) atomicAdd(&p.tile_hits[tile], n_hits);
+    }
     if (inside) {
         const int64_t bpix = (int64_t)b * HW + pix_id;
         p.final_prev_T[bpix] = pT;
@@ -260,30 +268,9 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 }
 
 // ---------------------------------------------------------------------------
-// backward
-//
-// Per chunk of 64 list entries (walked from the back of the tile list):
-//   A. coverage: as in the forward; every pixel thread gets a 64-bit mask `rem` of the chunk
-//      faces that cover it (positions >= its n_contrib masked off, backward.cu:192-194).
-//   B. per-pixel sequential part, in list order from the back: recover T (Q10), the running
-//      accum_rec terms and dL/dalpha (backward.cu:244-308).  Each pixel handles at most SLOTS
-//      hits per pass and parks (T, dL_dalpha) of hit #h in s_pool[pixel][h]; the pass mask of
-//      the pixel goes to s_pmask and, transposed by wave ballots, to s_cmask[face][quadrant].
-//   C. per-hit part, hit-parallel: the pass's hits are listed face-major (thread (face, quadrant)
-//      scatters its pixels into slots given by a block scan of the hit counts), then every lane
-//      takes ONE hit, recomputes the pixel-dependent geometry and the 23 gradient components of
-//      backward.cu:313-382, and a segmented wave scan (hits of a face are consecutive lanes)
-//      leaves each face's total in the last lane of its segment; only those lanes add into the
-//      per-face LDS sums (a handful of ds_add_f32 lanes per 64 hits instead of 23 per hit).
-//   After the last pass of a chunk the sums are flushed with packed global atomics: 3 vertex rows +
-//   1 face row per (tile, face) instead of the reference's 23 global atomics per (pixel, face)
-//   (backward.cu:389-418).
-// (Measured dead ends, kept out: 23 ds_add_f32 per hit -- 59 % of wave cycles stalled on LDS issue,
-//  LDS float atomics retire ~1 lane per 2.4 cycles; one thread per (face, quadrant) accumulating in
-//  registers -- no atomics but ~15 % lane utilisation on small triangles, 0.7 ms for C4.)
+// backward: shared helpers
 // ---------------------------------------------------------------------------
 constexpr int NACC = 23;  // 9 dverts, 9 dvcolor, 3 dvdepth, dopacity, dintense
-constexpr int BWD_SLOTS = 8;
 
 // DPP lane moves (VALU, no LDS traffic).  dpp_i: a lane whose source is outside its 16-lane row
 // (row_shr) or outside the written rows (row_bcast, row_mask) keeps `old`.  dpp_f_any: same move, but the
@@ -338,27 +325,44 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
     else DMR_SEG_LEVEL("row_bcast:31 row_mask:0xc bank_mask:0xf bound_ctrl:0");
 }
 
-__global__ void __launch_bounds__(256, 3)
-k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-               float* __restrict__ vrow, float* __restrict__ frow) {
+// ---------------------------------------------------------------------------
+// backward, kernel 1 of 2: k_tri_backward_pix -- the per-pixel sequential part.
+//
+// Per chunk of 64 list entries (walked from the back of the tile list):
+//   A. coverage as in the forward; every pixel gets a 64-bit mask `rem` of the chunk faces covering it
+//      (positions >= its n_contrib masked off, backward.cu:192-194).
+//   B. in list order from the back: recover T (Q10), the running accum_rec terms and dL/dalpha
+//      (backward.cu:244-308).  At most BWD_SLOTS hits per pixel per pass; (T, dL_dalpha) of hit #h is
+//      parked in s_pool[h][pixel].
+//   C. the pass's hits are listed FACE-major (ballot transposes + block scan + scatter) and written out
+//      as 16-byte HitRecords at the tile's offset (scan of the forward's per-tile hit counts).
+// Everything that needs 23 accumulators per face happens in kernel 2, so this kernel keeps the forward's
+// register/LDS footprint.  History of the fused versions (all measured at C4, see profiles/r01):
+// 23 ds_add_f32 per hit: 59 % of wave cycles stalled on LDS issue (1.26 ms); one thread per
+// (face, quadrant) accumulating in registers: ~15 % lane utilisation (1.25 ms); hit-parallel phase with a
+// segmented scan inside this kernel: 168 VGPRs + 50 KB LDS -> 3 waves/SIMD, 0.56 ms.
+// ---------------------------------------------------------------------------
+#ifndef DMR_BWD_SLOTS
+#define DMR_BWD_SLOTS 8
+#endif
+constexpr int BWD_SLOTS = DMR_BWD_SLOTS;
+
+__global__ void __launch_bounds__(256)
+k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits) {
     constexpr int CHUNK = 64;
-    static_assert(BWD_CHUNK == CHUNK, "phase C maps 4 quad lanes to each of 64 faces");
+    static_assert(BWD_CHUNK == CHUNK, "one thread per (face, quadrant) in the transposition");
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
-    __shared__ int s_vid[CHUNK][4];
-    __shared__ uint64_t s_cmask[CHUNK][4];       // [face][quadrant]: pixels of the quadrant that hit the face this pass
-    __shared__ uint64_t s_pmask[TILE_PIX];       // [pixel]: faces handled by the pixel this pass
+    __shared__ uint64_t s_cmask[CHUNK][4];          // [face][quadrant]: pixels of the quadrant that took the face this pass
+    __shared__ uint64_t s_pmask[TILE_PIX];          // [pixel]: faces handled by the pixel this pass
     __shared__ float2 s_pool[BWD_SLOTS][TILE_PIX];  // [hit ordinal from the back][pixel] = (T, dL_dalpha)
-    __shared__ float s_pix[7][TILE_PIX];         // ray d xyz, dL_dpixel rgb, dL_dpixel depth
-    __shared__ float s_acc[NACC][CHUNK];
-    __shared__ uint32_t s_touched[CHUNK];
     // s_mx (phase A hand-off) and s_hits (phase C hit list) are never live together: one buffer
     __shared__ uint32_t s_mx_hits[4 * 4 * 64];
     uint32_t (*s_mx)[4][64] = reinterpret_cast<uint32_t (*)[4][64]>(s_mx_hits);  // [quadrant][face block][lane]
     uint16_t* s_hits = reinterpret_cast<uint16_t*>(s_mx_hits);  // face-major hit list of a pass: face << 8 | pixel
     static_assert(sizeof(uint16_t) * TILE_PIX * BWD_SLOTS <= sizeof(uint32_t) * 4 * 4 * 64, "hit list fits");
     __shared__ int s_wsum[4];
-    __shared__ int s_fstart[64 + 1];
     __shared__ uint32_t s_max_last;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -373,6 +377,8 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
     const int tile = (b * p.gy + ty) * p.gx + tx;
     const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
     if (begin == end) return;  // uniform
+    uint32_t hit_cursor = p.hit_offset[tile];
+    if (hit_cursor == p.hit_offset[tile + 1]) return;  // no pixel of the tile blended anything
 
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
@@ -387,9 +393,10 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
         dpc1 = dL_dcolor[((int64_t)b * 3 + 1) * HW + pix_id];
         dpc2 = dL_dcolor[((int64_t)b * 3 + 2) * HW + pix_id];
         dpd = dL_ddepth[bpix];
+        // what kernel 2 needs of this pixel: ray direction and upstream gradient, two 16-byte gathers per hit
+        pixrec[2 * bpix] = make_float4(rd.x, rd.y, rd.z, dpd);
+        pixrec[2 * bpix + 1] = make_float4(dpc0, dpc1, dpc2, 0.f);
     }
-    s_pix[0][tid] = rd.x; s_pix[1][tid] = rd.y; s_pix[2][tid] = rd.z;
-    s_pix[3][tid] = dpc0; s_pix[4][tid] = dpc1; s_pix[5][tid] = dpc2; s_pix[6][tid] = dpd;
     // backward.cu:293-298 (loop invariant there)
     float bg_dot = 0.f;
     bg_dot += p.bg[0] * dpc0; bg_dot += p.bg[1] * dpc1; bg_dot += p.bg[2] * dpc2;
@@ -408,7 +415,7 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
     float acr0 = 0, acr1 = 0, acr2 = 0, acrd = 0;
     float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0;
 
-    // face-thread identity for phase C
+    // thread identity in the transposition
     const int fk = tid >> 2, fq = tid & 3;
 
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
@@ -416,11 +423,11 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
         const uint32_t hi = total - ci * CHUNK;  // chunk = list positions [lo, hi)
         const uint32_t lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
         const int n = (int)(hi - lo);
-        __syncthreads();  // previous chunk's flush is done with the LDS records
+        __syncthreads();  // previous chunk is done with the LDS records
         int big = 0;
         if (tid < n)
             big = stage_face(p, b, (int)p.face_list[begin + lo + tid], tx * TILE, ty * TILE, view_o,
-                             s_cov[tid], s_shade[tid], s_vid[tid]);
+                             s_cov[tid], s_shade[tid], nullptr);
         else if (tid < ((n + 31) & ~31)) stage_null(s_cov[tid]);
         const bool any_big = __syncthreads_or(big);
 
@@ -442,10 +449,6 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
             if (lim <= 0) rem = 0;
             else if (lim < 64) rem &= (1ull << lim) - 1ull;
         }
-
-        // per-face sums of this chunk live in LDS; only segment tails touch them (see C2)
-        for (int i = tid; i < NACC * CHUNK; i += 256) (&s_acc[0][0])[i] = 0.f;
-        if (tid < CHUNK) s_touched[tid] = 0u;
 
         while (__syncthreads_or(rem != 0ull)) {
             // ---- B: up to BWD_SLOTS hits of this pixel, from the back
@@ -508,11 +511,9 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
             }
             __syncthreads();
 
-            // ---- C1: face-major hit list of this pass.  Thread (fk, fq) owns the hits of face fk in
-            // quadrant fq; an exclusive block scan of the counts gives every hit a slot, so that
-            // consecutive slots belong to the same face.
+            // ---- C: face-major hit list of this pass.  Thread (fk, fq) owns the hits of face fk in quadrant fq;
+            // an exclusive block scan of the counts gives every hit a slot, consecutive slots = same face.
             uint64_t cm = (fk < n) ? s_cmask[fk][fq] : 0ull;
-            if (p.dbg & 2) cm = 0ull;
             const int cnt = __popcll(cm);
             int incl = cnt;
 #pragma unroll
@@ -530,129 +531,177 @@ k_tri_backward(TriParams p, const float* __restrict__ dL_dcolor, const float* __
                 if (w < wave) hbase += ws;
                 H += ws;
             }
-            if (fq == 0) s_fstart[fk] = hbase;  // first hit slot of face fk (4 quadrant runs follow each other)
-            if (tid == 0) s_fstart[CHUNK] = H;
             while (cm != 0ull) {
                 const int l = __ffsll((long long)cm) - 1;
                 cm &= cm - 1ull;
                 s_hits[hbase++] = (uint16_t)((fk << 8) | (fq * 64 + l));
             }
             __syncthreads();
-
-            // ---- C2: one hit per lane; 23 gradient components; segmented wave scan by face; the last
-            // lane of every segment adds the segment total into the per-face LDS sums.
-            // wave w owns faces [16w, 16w+16): no other wave touches their LDS sums, so segment tails can
-            // use plain read-modify-write instead of ds_add_f32
-            const int h_end = s_fstart[16 * wave + 16];
-            for (int i0h = s_fstart[16 * wave]; i0h < h_end; i0h += 64) {
-                const int hi_idx = i0h + lane;
-                const bool valid = hi_idx < h_end;
-                const uint32_t desc = valid ? (uint32_t)s_hits[hi_idx] : 0xffffu;
-                const int k = valid ? (int)(desc >> 8) : -1 - lane;  // invalid lanes: unique keys
-                float g[NACC];
-#pragma unroll
-                for (int c = 0; c < NACC; c++) g[c] = 0.f;
-                if (valid && !(p.dbg & 128)) {
-                    const int pp = (int)(desc & 0xffu);
-                    const ShadeRec& r = s_shade[k];
-                    const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
-                    const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
-                    const float c00 = r.c0[0], c01 = r.c0[1], c02 = r.c0[2];
-                    const float c10 = r.c1[0], c11 = r.c1[1], c12 = r.c1[2];
-                    const float c20 = r.c2[0], c21 = r.c2[1], c22 = r.c2[2];
-                    const float fd0 = r.d0, fd1 = r.d1, fd2 = r.d2, alpha = r.opacity, intense = r.intense;
-                    const uint64_t pmk = s_pmask[pp];
-                    const int ord = __popcll(k < 63 ? (pmk >> (k + 1)) : 0ull);  // hits of that pixel behind face k
-                    const float2 rec = s_pool[ord][pp];
-                    const V3 d = {s_pix[0][pp], s_pix[1][pp], s_pix[2][pp]};
-                    const float g0 = s_pix[3][pp], g1 = s_pix[4][pp], g2 = s_pix[5][pp], gdp = s_pix[6][pp];
-                    const float Th = rec.x;
-
-                    const V3 Pv = cross(d, E2);
-                    const float denom = dot(Pv, E1);
-                    const float inv_denom = fast_rcp(denom);
-                    const float nu = dot(Pv, Tv);
-                    const float iu = nu * inv_denom;
-                    const float iv = dot(Q, d) * inv_denom;
-                    float iuc, ivc; int code;
-                    clamp_bary_uv(iu, iv, iuc, ivc, code);
-                    const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
-                    const float dic0 = g0 * alpha * Th, dic1 = g1 * alpha * Th, dic2 = g2 * alpha * Th;
-                    const float did = gdp * alpha * Th;
-
-                    float dL_di0 = 0, dL_di1 = 0, dL_di2 = 0, dfint = 0;
-                    dL_di0 += c00 * dic0 * intense; dL_di1 += c10 * dic0 * intense; dL_di2 += c20 * dic0 * intense;
-                    dfint += (i0 * c00 + i1 * c10 + i2 * c20) * dic0;
-                    dL_di0 += c01 * dic1 * intense; dL_di1 += c11 * dic1 * intense; dL_di2 += c21 * dic1 * intense;
-                    dfint += (i0 * c01 + i1 * c11 + i2 * c21) * dic1;
-                    dL_di0 += c02 * dic2 * intense; dL_di1 += c12 * dic2 * intense; dL_di2 += c22 * dic2 * intense;
-                    dfint += (i0 * c02 + i1 * c12 + i2 * c22) * dic2;
-                    dL_di0 += fd0 * did; dL_di1 += fd1 * did; dL_di2 += fd2 * did;
-
-                    float duc_du, duc_dv, dvc_du, dvc_dv;
-                    clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
-                    const float di0_diu = -1.f * duc_du + -1.f * dvc_du, di0_div = -1.f * duc_dv + -1.f * dvc_dv;
-                    const float di1_diu = 1.f * duc_du + 0.f * dvc_du, di1_div = 1.f * duc_dv + 0.f * dvc_dv;
-                    const float di2_diu = 0.f * duc_du + 1.f * dvc_du, di2_div = 0.f * duc_dv + 1.f * dvc_dv;
-                    const float dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
-                    const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
-
-                    // ray_tri_intersection_grad (auxiliary.h:288-333), Q11/Q12 kept
-                    const float dsq = denom, den2 = dsq * dsq, dinv = fast_rcp(den2);
-                    const float v0 = nu, v1 = dsq, v2 = dot(Q, E2);
-                    const V3 du_dE1 = (-1.0f * Pv * v0) * dinv;
-                    const V3 du_dE2 = (cross(Tv, d) * v1 - v0 * cross(E1, d)) * dinv;
-                    const V3 du_dT = (Pv * v1) * dinv;
-                    const V3 dv_dE1 = ((cross(E2, Tv) * v1) - (v2 * Pv)) * dinv;
-                    const V3 dv_dE2 = ((Q * v1) - (v2 * cross(E1, d))) * dinv;
-                    const V3 dv_dT = cross(E1, E2) * v1 * dinv;
-                    const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
-                    const V3 dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
-                    const V3 dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
-                    const V3 dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
-
-                    g[0] = dp0.x; g[1] = dp0.y; g[2] = dp0.z;
-                    g[3] = dp1.x; g[4] = dp1.y; g[5] = dp1.z;
-                    g[6] = dp2.x; g[7] = dp2.y; g[8] = dp2.z;
-                    g[9] = i0 * dic0 * intense; g[10] = i0 * dic1 * intense; g[11] = i0 * dic2 * intense;
-                    g[12] = i1 * dic0 * intense; g[13] = i1 * dic1 * intense; g[14] = i1 * dic2 * intense;
-                    g[15] = i2 * dic0 * intense; g[16] = i2 * dic1 * intense; g[17] = i2 * dic2 * intense;
-                    g[18] = i0 * did; g[19] = i1 * did; g[20] = i2 * did;
-                    g[21] = rec.y; g[22] = dfint;
-                }
-                // segmented inclusive scan over the wave (hits of one face are consecutive lanes): four
-                // row-local DPP levels, then the two row-broadcast levels of the classic wave scan
-                if (!(p.dbg & 64)) {
-                    seg_scan_level<DPP_ROW_SHR + 1, 0xF>(k, g);
-                    seg_scan_level<DPP_ROW_SHR + 2, 0xF>(k, g);
-                    seg_scan_level<DPP_ROW_SHR + 4, 0xF>(k, g);
-                    seg_scan_level<DPP_ROW_SHR + 8, 0xF>(k, g);
-                    seg_scan_level<DPP_ROW_BCAST15, 0xA>(k, g);
-                    seg_scan_level<DPP_ROW_BCAST31, 0xC>(k, g);
-                }
-                const int kn = __shfl_down(k, 1, 64);
-                if (valid && (lane == 63 || kn != k) && !(p.dbg & 256)) {  // segment tail holds the segment total
-#pragma unroll
-                    for (int c = 0; c < NACC; c++) s_acc[c][k] += g[c];
-                    s_touched[k] = 1u;
-                }
+            // write the records (coalesced 16-byte stores)
+            for (int i = tid; i < H; i += 256) {
+                const uint32_t desc = s_hits[i];
+                const int k = (int)(desc >> 8), pp = (int)(desc & 0xffu);
+                const uint64_t pmk = s_pmask[pp];
+                const int ord = __popcll(k < 63 ? (pmk >> (k + 1)) : 0ull);  // hits of that pixel behind face k
+                const float2 rec = s_pool[ord][pp];
+                const int q = pp >> 6, l = pp & 63;
+                const int hx = tx * TILE + (q & 1) * 8 + (l & 7), hy = ty * TILE + (q >> 1) * 8 + (l >> 3);
+                HitRecord hr;
+                hr.entry = begin + lo + (uint32_t)k;
+                hr.pixel = (uint32_t)((int64_t)b * HW + (int64_t)p.W * hy + hx);
+                hr.T = rec.x; hr.dL_dalpha = rec.y;
+                hits[hit_cursor + i] = hr;
             }
+            hit_cursor += (uint32_t)H;
             // the loop-top __syncthreads_or keeps pass k+1 from overwriting s_pool/s_pmask/s_cmask/s_hits early
         }
-        __syncthreads();
+    }
+}
 
-        // flush: 32 lanes per face = 3 vertex rows x 8 + face row x 8 (2 used); 8 faces per sweep
-        const int sub = tid & 31, grp = sub >> 3, comp = sub & 7;
-        for (int f0 = 0; f0 < n; f0 += 8) {
-            const int k = f0 + (tid >> 5);
-            if (k >= n || !s_touched[k] || (p.dbg & 1)) continue;
-            if (grp < 3) {
-                if (comp == 7) continue;
-                const int ai = comp < 3 ? grp * 3 + comp : (comp < 6 ? 9 + grp * 3 + (comp - 3) : 18 + grp);
-                atomicAdd(&vrow[((int64_t)b * p.P + s_vid[k][grp]) * VROW + comp], s_acc[ai][k]);
-            } else if (comp < 2) {
-                atomicAdd(&frow[((int64_t)b * p.F + s_vid[k][3]) * FROW + comp], s_acc[21 + comp][k]);
+// ---------------------------------------------------------------------------
+// backward, kernel 2 of 2: k_tri_backward_hits -- one lane per blended (pixel, face) pair.
+//
+// Flat over the hit records (face-major inside every (tile, chunk, pass) group), no workgroup barriers.
+// Each lane gathers its face and pixel data, recomputes the pixel-dependent geometry and the 23 gradient
+// components of backward.cu:313-382; a segmented DPP wave scan keyed by the list entry leaves each
+// entry's total in the last lane of its segment; segment totals are staged in wave-private LDS and flushed
+// with PACKED global atomics: 3 vertex rows + 1 face row per segment (4 memory-side requests) instead of
+// the reference's 23 global atomics per (pixel, face) (backward.cu:389-418).
+// ---------------------------------------------------------------------------
+constexpr int STAGE_SEGS = 16;  // segment totals staged per flush round and wave
+
+__global__ void __launch_bounds__(256)
+k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits,
+                    uint32_t nhits, float* __restrict__ vrow, float* __restrict__ frow) {
+    __shared__ float s_stage[4][STAGE_SEGS][28];  // 23 sums, v0, v1, v2, face, view
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t HW = (int64_t)p.H * p.W;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < nhits; base += stride) {
+        const uint32_t hi_idx = base + lane;
+        const bool valid = hi_idx < nhits;
+        int k = -1 - lane;  // invalid lanes: unique keys
+        int v0 = 0, v1 = 0, v2 = 0, face = 0, b = 0;
+        float g[NACC];
+#pragma unroll
+        for (int c = 0; c < NACC; c++) g[c] = 0.f;
+        if (valid) {
+            const HitRecord hr = hits[hi_idx];
+            k = (int)hr.entry;
+            face = (int)p.face_list[hr.entry];
+            b = (int)(hr.pixel / (uint32_t)HW);
+            v0 = p.faces[3 * face]; v1 = p.faces[3 * face + 1]; v2 = p.faces[3 * face + 2];
+            const float4 pr0 = pixrec[2 * (int64_t)hr.pixel], pr1 = pixrec[2 * (int64_t)hr.pixel + 1];
+            const V3 d = {pr0.x, pr0.y, pr0.z};
+            const float gdp = pr0.w, g0 = pr1.x, g1 = pr1.y, g2 = pr1.z;
+            const V3 p0 = load_v3(p.verts, v0), p1 = load_v3(p.verts, v1), p2 = load_v3(p.verts, v2);
+            const V3 cc0 = load_v3(p.verts_color, v0), cc1 = load_v3(p.verts_color, v1), cc2 = load_v3(p.verts_color, v2);
+            const float fd0 = p.vproj[(int64_t)b * p.P + v0].w, fd1 = p.vproj[(int64_t)b * p.P + v1].w,
+                        fd2 = p.vproj[(int64_t)b * p.P + v2].w;
+            const float alpha = p.faces_opacity[face], intense = p.faces_intense[(int64_t)b * p.F + face];
+            const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
+            const V3 Tv = view_o - p0, E1 = p1 - p0, E2 = p2 - p0;
+            const V3 Q = cross(Tv, E1);
+            const float c00 = cc0.x, c01 = cc0.y, c02 = cc0.z, c10 = cc1.x, c11 = cc1.y, c12 = cc1.z;
+            const float c20 = cc2.x, c21 = cc2.y, c22 = cc2.z;
+            const float Th = hr.T;
+
+            const V3 Pv = cross(d, E2);
+            const float denom = dot(Pv, E1);
+            const float inv_denom = fast_rcp(denom);
+            const float nu = dot(Pv, Tv);
+            const float iu = nu * inv_denom;
+            const float iv = dot(Q, d) * inv_denom;
+            float iuc, ivc; int code;
+            clamp_bary_uv(iu, iv, iuc, ivc, code);
+            const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
+            const float dic0 = g0 * alpha * Th, dic1 = g1 * alpha * Th, dic2 = g2 * alpha * Th;
+            const float did = gdp * alpha * Th;
+
+            float dL_di0 = 0, dL_di1 = 0, dL_di2 = 0, dfint = 0;
+            dL_di0 += c00 * dic0 * intense; dL_di1 += c10 * dic0 * intense; dL_di2 += c20 * dic0 * intense;
+            dfint += (i0 * c00 + i1 * c10 + i2 * c20) * dic0;
+            dL_di0 += c01 * dic1 * intense; dL_di1 += c11 * dic1 * intense; dL_di2 += c21 * dic1 * intense;
+            dfint += (i0 * c01 + i1 * c11 + i2 * c21) * dic1;
+            dL_di0 += c02 * dic2 * intense; dL_di1 += c12 * dic2 * intense; dL_di2 += c22 * dic2 * intense;
+            dfint += (i0 * c02 + i1 * c12 + i2 * c22) * dic2;
+            dL_di0 += fd0 * did; dL_di1 += fd1 * did; dL_di2 += fd2 * did;
+
+            float duc_du, duc_dv, dvc_du, dvc_dv;
+            clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
+            const float di0_diu = -1.f * duc_du + -1.f * dvc_du, di0_div = -1.f * duc_dv + -1.f * dvc_dv;
+            const float di1_diu = 1.f * duc_du + 0.f * dvc_du, di1_div = 1.f * duc_dv + 0.f * dvc_dv;
+            const float di2_diu = 0.f * duc_du + 1.f * dvc_du, di2_div = 0.f * duc_dv + 1.f * dvc_dv;
+            const float dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
+            const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
+
+            // ray_tri_intersection_grad (auxiliary.h:288-333), Q11/Q12 kept
+            const float dsq = denom, den2 = dsq * dsq, dinv = fast_rcp(den2);
+            const float w0 = nu, w1 = dsq, w2 = dot(Q, E2);
+            const V3 du_dE1 = (-1.0f * Pv * w0) * dinv;
+            const V3 du_dE2 = (cross(Tv, d) * w1 - w0 * cross(E1, d)) * dinv;
+            const V3 du_dT = (Pv * w1) * dinv;
+            const V3 dv_dE1 = ((cross(E2, Tv) * w1) - (w2 * Pv)) * dinv;
+            const V3 dv_dE2 = ((Q * w1) - (w2 * cross(E1, d))) * dinv;
+            const V3 dv_dT = cross(E1, E2) * w1 * dinv;
+            const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
+            const V3 dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
+            const V3 dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
+            const V3 dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
+
+            g[0] = dp0.x; g[1] = dp0.y; g[2] = dp0.z;
+            g[3] = dp1.x; g[4] = dp1.y; g[5] = dp1.z;
+            g[6] = dp2.x; g[7] = dp2.y; g[8] = dp2.z;
+            g[9] = i0 * dic0 * intense; g[10] = i0 * dic1 * intense; g[11] = i0 * dic2 * intense;
+            g[12] = i1 * dic0 * intense; g[13] = i1 * dic1 * intense; g[14] = i1 * dic2 * intense;
+            g[15] = i2 * dic0 * intense; g[16] = i2 * dic1 * intense; g[17] = i2 * dic2 * intense;
+            g[18] = i0 * did; g[19] = i1 * did; g[20] = i2 * did;
+            g[21] = hr.dL_dalpha; g[22] = dfint;
+        }
+        // segmented inclusive scan over the wave (hits of one entry are consecutive lanes): four row-local
+        // DPP levels, then the two row-broadcast levels of the classic wave scan
+        seg_scan_level<DPP_ROW_SHR + 1, 0xF>(k, g);
+        seg_scan_level<DPP_ROW_SHR + 2, 0xF>(k, g);
+        seg_scan_level<DPP_ROW_SHR + 4, 0xF>(k, g);
+        seg_scan_level<DPP_ROW_SHR + 8, 0xF>(k, g);
+        seg_scan_level<DPP_ROW_BCAST15, 0xA>(k, g);
+        seg_scan_level<DPP_ROW_BCAST31, 0xC>(k, g);
+
+        // segment tails hold the totals; stage them (wave-private LDS) and flush with packed atomics
+        const int kn = __shfl_down(k, 1, 64);
+        const bool tail = valid && (lane == 63 || kn != k);
+        const uint64_t tmask = __ballot(tail);
+        const int ntail = __popcll(tmask);
+        const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+        for (int r0 = 0; r0 < ntail; r0 += STAGE_SEGS) {
+            if (tail && rank >= r0 && rank < r0 + STAGE_SEGS) {
+                float* st = s_stage[wave][rank - r0];
+#pragma unroll
+                for (int c = 0; c < NACC; c++) st[c] = g[c];
+                st[23] = __int_as_float(v0); st[24] = __int_as_float(v1); st[25] = __int_as_float(v2);
+                st[26] = __int_as_float(face); st[27] = __int_as_float(b);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nseg = min(STAGE_SEGS, ntail - r0);
+            // 32 lanes per segment = 3 vertex rows x 8 + face row x 8 (2 used); 2 segments per sweep
+            const int sub = lane & 31, grp = sub >> 3, comp = sub & 7;
+            for (int s0 = 0; s0 < nseg; s0 += 2) {
+                const int sg = s0 + (lane >> 5);
+                if (sg >= nseg) continue;
+                const float* st = s_stage[wave][sg];
+                const int sb = __float_as_int(st[27]);
+                if (grp < 3) {
+                    if (comp == 7) continue;
+                    const int ai = comp < 3 ? grp * 3 + comp : (comp < 6 ? 9 + grp * 3 + (comp - 3) : 18 + grp);
+                    atomicAdd(&vrow[((int64_t)sb * p.P + __float_as_int(st[23 + grp])) * VROW + comp], st[ai]);
+                } else if (comp < 2) {
+                    atomicAdd(&frow[((int64_t)sb * p.F + __float_as_int(st[26])) * FROW + comp], st[21 + comp]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -694,6 +743,7 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, const f
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
+    p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset;
     return p;
 }
 
@@ -706,13 +756,25 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
     k_tri_forward<FWD_CHUNK><<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, out_color, out_depth);
 }
 
-void launch_tri_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
-                         const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
-                         const float* dL_dcolor, const float* dL_ddepth, float* vrow, float* frow, hipStream_t st) {
+void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
+                             const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
+                             const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
+                             hipStream_t st) {
     if (r1 <= r0) return;
     TriParams p = make_params(s, gx, gy, r0, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
-    k_tri_backward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, vrow, frow);
+    k_tri_backward_pix<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits);
+}
+
+void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
+                              const float4* pixrec, const HitRecord* hits, uint32_t nhits, float* vrow, float* frow,
+                              hipStream_t st) {
+    if (nhits == 0) return;
+    TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    TriParams p = make_params(s, 0, 0, 0, vproj, nullptr, face_list, none);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((nhits + 255u) / 256u, 256u * 16u);
+    StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
+    k_tri_backward_hits<<<dim3(blocks), dim3(256), 0, st>>>(p, pixrec, hits, nhits, vrow, frow);
 }
 
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,

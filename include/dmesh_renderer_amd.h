@@ -108,7 +108,8 @@ int64_t dmr_export(const dmr_scene* scene, int is_tet, int num_rendered, const c
 enum {
     DMR_STAGE_PROJECT = 0, DMR_STAGE_SETUP_FACES = 1, DMR_STAGE_SCAN = 2, DMR_STAGE_SCATTER = 3,
     DMR_STAGE_SORT = 4, DMR_STAGE_TRI_FORWARD = 5, DMR_STAGE_TRI_BACKWARD = 6, DMR_STAGE_TRI_UNPACK = 7,
-    DMR_STAGE_TET_FIRST = 8, DMR_STAGE_TET_FORWARD = 9, DMR_STAGE_TET_BACKWARD = 10, DMR_NUM_STAGES = 11
+    DMR_STAGE_TET_FIRST = 8, DMR_STAGE_TET_FORWARD = 9, DMR_STAGE_TET_BACKWARD = 10,
+    DMR_STAGE_TRI_BACKWARD_HITS = 11, DMR_NUM_STAGES = 12
 };
 void dmr_profile_enable(uint32_t mask);
 /* Waits for the recorded events, ADDS each stage's elapsed milliseconds / launch count into

@@ -39,7 +39,7 @@ def test_binding_loads_and_reports_arch():
     lib = _lib.load()
     assert lib.dmr_build_arch() == b"gfx950"
     assert lib.dmr_abi_version() == _lib.ABI_VERSION
-    assert lib.dmr_stage_name(6) == b"k_tri_backward"
+    assert lib.dmr_stage_name(6) == b"k_tri_backward_pix" and lib.dmr_stage_name(11) == b"k_tri_backward_hits"
 
 
 def test_scene_struct_layout_matches_header():
