@@ -15,6 +15,8 @@
 // order and equals the order of the reference's STABLE sort, whose ties keep emission
 // order = ascending face id (Q6).  The result -- per-tile face lists and ranges -- is
 // bit-identical to the reference's sorted list, whatever order the scatter ran in.
+#include <algorithm>
+
 #include "dmr_kernels.hpp"
 
 namespace dmr {
@@ -292,6 +294,7 @@ k_scatter_faces(int B, int F, int gx, int gy, const uint2* __restrict__ face_rec
 //    longer segments run the same network in place in global memory.
 // ---------------------------------------------------------------------------
 constexpr int SORT_LDS_KEYS = 4096;  // 32 KiB
+constexpr uint32_t RANK_SORT_MAX = 512;
 
 template <class Ptr>
 __device__ __forceinline__ void bitonic_pass(Ptr a, uint32_t n, uint32_t npow2, uint32_t tid, uint32_t nthreads, bool global_mem) {
@@ -323,17 +326,37 @@ __device__ __forceinline__ void bitonic_pass(Ptr a, uint32_t n, uint32_t npow2, 
 }
 
 __global__ void __launch_bounds__(256)
-k_sort_tiles(const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ keys,
+k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ keys,
              uint32_t* __restrict__ face_list) {
     __shared__ uint64_t s_keys[SORT_LDS_KEYS];
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    // grid-stride over tiles: most tiles of a frame are empty, a workgroup launch per tile costs more than the sort
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
     const uint32_t n = end - begin;
-    if (n == 0) return;
-    const uint32_t tid = threadIdx.x;
+    if (n == 0) continue;
+    __syncthreads();  // the previous tile's keys are no longer needed
     uint32_t npow2 = 1;
     while (npow2 < n) npow2 <<= 1;
-    if (n <= SORT_LDS_KEYS) {
+    if (n <= RANK_SORT_MAX) {
+        // Short segments (the common case: C4 averages 315 entries per busy tile): rank sort.  Keys are
+        // unique, so the number of smaller keys IS the output slot; every thread streams all n keys as
+        // LDS broadcasts -- no barriers, no dependent steps (the 45-step bitonic network was latency bound).
+        for (uint32_t i = tid; i < n; i += 256) s_keys[i] = keys[begin + i];
+        __syncthreads();
+        const uint32_t e0 = tid, e1 = tid + 256;
+        const uint64_t k0 = e0 < n ? s_keys[e0] : ~0ull, k1 = e1 < n ? s_keys[e1] : ~0ull;
+        uint32_t r0 = 0, r1 = 0;
+        if (n <= 256) {
+#pragma unroll 8
+            for (uint32_t j = 0; j < n; j++) r0 += s_keys[j] < k0 ? 1u : 0u;
+        } else {
+#pragma unroll 8
+            for (uint32_t j = 0; j < n; j++) { const uint64_t kj = s_keys[j]; r0 += kj < k0 ? 1u : 0u; r1 += kj < k1 ? 1u : 0u; }
+        }
+        if (e0 < n) { keys[begin + r0] = k0; face_list[begin + r0] = (uint32_t)k0; }
+        if (e1 < n) { keys[begin + r1] = k1; face_list[begin + r1] = (uint32_t)k1; }
+    } else if (n <= SORT_LDS_KEYS) {
         for (uint32_t i = tid; i < n; i += 256) s_keys[i] = keys[begin + i];
         __syncthreads();
         if (n > 1) bitonic_pass(s_keys, n, npow2, tid, 256, false);
@@ -346,6 +369,7 @@ k_sort_tiles(const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ ke
         uint64_t* g = keys + begin;
         bitonic_pass(g, n, npow2, tid, 256, true);
         for (uint32_t i = tid; i < n; i += 256) face_list[begin + i] = (uint32_t)g[i];
+    }
     }
 }
 
@@ -418,7 +442,7 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, hipStream_t st) {
     if (ntiles == 0) return;
     StageScope t(DMR_STAGE_SORT, st);
-    k_sort_tiles<<<dim3((unsigned)ntiles), dim3(256), 0, st>>>(tile_offset, keys, face_list);
+    k_sort_tiles<<<dim3((unsigned)std::min(ntiles, 256 * 5)), dim3(256), 0, st>>>((uint32_t)ntiles, tile_offset, keys, face_list);
 }
 
 }  // namespace dmr
