@@ -145,8 +145,15 @@ def main():
     dom = max((FWD, BWD1, BWD2), key=lambda i: ms[i])
     dom_ms = ms[dom] / max(1, cnt[dom])
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes,
+    # scripts/prof_traffic.sh): measured offline with rocprofv3 on the same workload and committed under profiles/
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01", f"traffic_{a.config.lower()}.json")
+    if world == 1 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = tj.get("dmr::" + lib.dmr_stage_name(dom).decode(), {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": lib.dmr_stage_name(dom).decode(), "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_ms": round(dom_ms, 4), "algorithmic_bytes": alg[dom],
                 "note": "composite kernels are VALU/latency-bound (256 coverage tests per list entry, ~450 flops per hit), see DESIGN.md"}
 
