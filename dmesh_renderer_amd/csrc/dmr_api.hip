@@ -10,6 +10,8 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -76,9 +78,11 @@ size_t carve_image(void* b, size_t ntiles, size_t npix, bool tet, ImageState& s)
     }
     return c.off;
 }
+// face_list first: the backward re-derives it from the buffer start, whatever capacity the forward
+// gave the buffer (speculative sizing allocates more than R entries)
 size_t carve_binning(void* b, size_t R, BinningState& s) {
     Carver c(b);
-    s.keys = c.take<uint64_t>(R); s.face_list = c.take<uint32_t>(R);
+    s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
     return c.off;
 }
 
@@ -104,18 +108,41 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     return 0;
 }
 
-// pinned landing pad for the num_rendered read, one per host thread
-int* pinned_slot() {
-    thread_local int* slot = nullptr;
-    if (!slot) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&slot), 64, hipHostMallocDefault) != hipSuccess) slot = nullptr;
+// pinned landing pad + event for the 4/8-byte size reads, one per host thread
+struct SizeRead { void* slot = nullptr; hipEvent_t ev = nullptr; };
+SizeRead* size_read() {
+    thread_local SizeRead sr;
+    if (!sr.slot) {
+        if (hipHostMalloc(&sr.slot, 64, hipHostMallocDefault) != hipSuccess) { sr.slot = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     }
-    return slot;
+    return &sr;
 }
 
-// stages shared by both renderers up to the sorted per-tile lists
-int run_binning(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc, void* ctx, hipStream_t st,
-                PointState& ps, FaceState& fs, ImageState& is, BinningState& bs, int* num_rendered) {
+// Speculative sizing.  The sizes of the binning buffer (R) and of the hit-record
+// buffer are only known on the device.  The reference stalls the pipeline on a device->host read before
+// it can continue (rasterizer_impl.cu:287-299).  Here the previous call with the same problem dimensions
+// provides a capacity guess (+25 %): the buffer is allocated and ALL remaining kernels are enqueued before
+// the host waits -- and it waits on an event recorded right after the size copy, not on the stream, so the
+// GPU keeps running.  Kernels clamp their writes to the capacity; if the exact size turns out larger the
+// affected stages are simply enqueued again with an exact buffer (first call, or a scene that grew > 25 %).
+struct SizeKey {
+    int v[9];
+    bool operator<(const SizeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+struct SizeGuess { uint64_t rendered = 0, hits = 0; };
+std::mutex g_size_mu;
+std::map<SizeKey, SizeGuess> g_size_cache;
+SizeKey size_key(const dmr_scene* s, bool tet, const Dims& d) {
+    return SizeKey{{s->B, s->P, s->F, s->T, s->W, s->H, d.r0, d.r1, tet ? 1 : 0}};
+}
+uint64_t padded(uint64_t n) { return n + n / 4 + 4096; }
+
+// Stages shared by both renderers up to the sorted per-tile lists, then `render` (the renderer's own
+// kernels, which only need the binning state).  See "Speculative sizing" above for the control flow.
+int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc, void* ctx, hipStream_t st,
+                PointState& ps, FaceState& fs, ImageState& is, int* num_rendered,
+                const std::function<void(const BinningState&)>& render) {
     PointState tp; FaceState tf; ImageState ti;
     void* pb = alloc(ctx, DMR_BUF_POINT, carve_point(nullptr, d.BP, tp));
     void* fb = alloc(ctx, DMR_BUF_FACE, carve_face(nullptr, d.BF, tet, tf));
@@ -124,28 +151,57 @@ int run_binning(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     carve_point(pb, d.BP, ps);
     carve_face(fb, d.BF, tet, fs);
     carve_image(ib, (size_t)d.ntiles, d.npix, tet, is);
+    SizeRead* sr = size_read();
+    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
+    int* host_R = reinterpret_cast<int*>(sr->slot);
 
-    DMR_HIP(hipMemsetAsync(is.tile_count, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
-    dmr::launch_project_verts(*s, ps.vproj, st);
-    dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
-                            fs.tiles_touched, is.tile_count, st);
-    dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, st);
-    int* host_R = pinned_slot();
-    if (!host_R) return fail("hipHostMalloc failed");
+    auto front = [&]() -> int {
+        DMR_HIP(hipMemsetAsync(is.tile_count, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
+        dmr::launch_project_verts(*s, ps.vproj, st);
+        dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
+                                fs.tiles_touched, is.tile_count, st);
+        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, st);
+        return 0;
+    };
+    auto rest = [&](uint64_t capacity) -> int {
+        BinningState tb, bs;
+        void* bb = alloc(ctx, DMR_BUF_BINNING, carve_binning(nullptr, (size_t)capacity, tb));
+        if (!bb && capacity > 0) return fail("binning allocation failed");
+        carve_binning(bb, (size_t)capacity, bs);
+        if (capacity > 0) {
+            dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
+                                      (uint32_t)capacity, st);
+            dmr::launch_sort_tiles(d.ntiles, is.tile_offset, bs.keys, bs.face_list, st);
+        }
+        if (!tet) DMR_HIP(hipMemsetAsync(is.tile_hits, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
+        render(bs);
+        return 0;
+    };
+
+    const SizeKey key = size_key(s, tet, d);
+    uint64_t guess = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_size_mu);
+        auto it = g_size_cache.find(key);
+        if (it != g_size_cache.end() && it->second.rendered) guess = std::min<uint64_t>(padded(it->second.rendered), 0x7fffffffu);
+    }
+    if (front()) return 1;
     DMR_HIP(hipMemcpyAsync(host_R, is.num_rendered, sizeof(int), hipMemcpyDeviceToHost, st));
-    DMR_HIP(hipStreamSynchronize(st));  // the one host wait of the forward pass (rasterizer_impl.cu:287-292)
+    DMR_HIP(hipEventRecord(sr->ev, st));
+    if (guess && rest(guess)) return 1;
+    DMR_HIP(hipEventSynchronize(sr->ev));  // the forward's one host wait (rasterizer_impl.cu:287-292): 4 bytes
     const int R = *host_R;
     if (R < 0) return fail("num_rendered overflows 31 bits");
     *num_rendered = R;
-
-    BinningState tb;
-    void* bb = alloc(ctx, DMR_BUF_BINNING, carve_binning(nullptr, (size_t)R, tb));
-    if (!bb && R > 0) return fail("binning allocation failed");
-    carve_binning(bb, (size_t)R, bs);
-    if (R > 0) {
-        dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
-                                  (uint32_t)R, st);
-        dmr::launch_sort_tiles(d.ntiles, is.tile_offset, bs.keys, bs.face_list, st);
+    if (!guess) {
+        if (rest((uint64_t)R)) return 1;
+    } else if ((uint64_t)R > guess) {  // the guess was too small: redo binning + render with the exact size
+        DMR_HIP(hipStreamSynchronize(st));
+        if (front() || rest((uint64_t)R)) return 1;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_size_mu);
+        g_size_cache[key].rendered = (uint64_t)std::max(R, 1);
     }
     DMR_HIP(hipGetLastError());
     return 0;
@@ -230,14 +286,13 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     *num_rendered = 0;
     if (s->P == 0 || s->F == 0) return 0;  // render.cu:105 (and Q16: F == 0)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    PointState ps; FaceState fs; ImageState is; BinningState bs;
-    if (run_binning(s, false, d, alloc, ctx, st, ps, fs, is, bs, num_rendered)) return 1;
-    DMR_HIP(hipMemsetAsync(is.tile_hits, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
-    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
-    dmr::launch_tri_forward(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
-                            out_depth, st);
-    DMR_HIP(hipGetLastError());
-    return 0;
+    PointState ps; FaceState fs; ImageState is;
+    auto render = [&](const BinningState& bs) {
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
+        dmr::launch_tri_forward(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
+                                out_depth, st);
+    };
+    return run_forward(s, false, d, alloc, ctx, st, ps, fs, is, num_rendered, render);
 }
 
 int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL_ddepth, int num_rendered,
@@ -267,28 +322,54 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, bs);
 
     // The forward counted the blended (pixel, face) pairs per tile; their scan places every tile's hit
-    // records and the total sizes the record buffer (the backward's one 8-byte host read).
+    // records and the total sizes the record buffer (the backward's one 8-byte host read; speculative
+    // sizing as in the forward).
+    SizeRead* sr = size_read();
+    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
+    unsigned long long* host_total = reinterpret_cast<unsigned long long*>(sr->slot);
+    const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
+    const size_t pbytes = up(sizeof(float4) * 2 * d.npix);
+    auto rest = [&](uint64_t capacity) -> int {
+        const size_t hbytes = up(sizeof(dmr::HitRecord) * (size_t)capacity);
+        char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes + pbytes + hbytes));
+        if (!work) return fail("workspace allocation failed");
+        float* vrow = reinterpret_cast<float*>(work);
+        float* frow = reinterpret_cast<float*>(work + vbytes);
+        float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
+        dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
+        DMR_HIP(hipMemsetAsync(work, 0, vbytes + fbytes, st));
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
+        dmr::launch_tri_backward_pix(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img,
+                                     dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity, st);
+        dmr::launch_tri_backward_hits(*s, ps.vproj, bs.face_list, pixrec, hits, is.hit_total, (uint32_t)capacity,
+                                      vrow, frow, st);
+        dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
+        return 0;
+    };
+    const SizeKey key = size_key(s, false, d);
+    uint64_t guess = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_size_mu);
+        auto it = g_size_cache.find(key);
+        if (it != g_size_cache.end() && it->second.hits) guess = std::min<uint64_t>(padded(it->second.hits), 0xfffffffeull);
+    }
     dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, st);
-    unsigned long long* host_total = reinterpret_cast<unsigned long long*>(pinned_slot());
-    if (!host_total) return fail("hipHostMalloc failed");
     DMR_HIP(hipMemcpyAsync(host_total, is.hit_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    DMR_HIP(hipStreamSynchronize(st));
+    DMR_HIP(hipEventRecord(sr->ev, st));
+    if (guess && rest(guess)) return 1;
+    DMR_HIP(hipEventSynchronize(sr->ev));
     const unsigned long long nhits = *host_total;
     if (nhits >= 0xffffffffull) return fail("more than 2^32 blended (pixel, face) pairs");
-    const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
-    const size_t pbytes = up(sizeof(float4) * 2 * d.npix), hbytes = up(sizeof(dmr::HitRecord) * (size_t)nhits);
-    char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes + pbytes + hbytes));
-    if (!work) return fail("workspace allocation failed");
-    float* vrow = reinterpret_cast<float*>(work);
-    float* frow = reinterpret_cast<float*>(work + vbytes);
-    float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
-    dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
-    DMR_HIP(hipMemsetAsync(work, 0, vbytes + fbytes, st));
-    dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
-    dmr::launch_tri_backward_pix(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, dL_dcolor,
-                                 dL_ddepth, pixrec, hits, st);
-    dmr::launch_tri_backward_hits(*s, ps.vproj, bs.face_list, pixrec, hits, (uint32_t)nhits, vrow, frow, st);
-    dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
+    if (!guess) {
+        if (rest(nhits)) return 1;
+    } else if (nhits > guess) {
+        DMR_HIP(hipStreamSynchronize(st));
+        if (rest(nhits)) return 1;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_size_mu);
+        g_size_cache[key].hits = std::max<uint64_t>(nhits, 1);
+    }
     DMR_HIP(hipGetLastError());
     return 0;
 }
@@ -300,15 +381,15 @@ int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, floa
     if (!alloc || !num_rendered || !out_color || !out_depth || !out_active) return fail("null argument");
     *num_rendered = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    PointState ps; FaceState fs; ImageState is; BinningState bs;
-    if (run_binning(s, true, d, alloc, ctx, st, ps, fs, is, bs, num_rendered)) return 1;
-    dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
-                           is.last_face, is.last_tet, is.is_active};
-    dmr::launch_tet_first_intersect(*s, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
-                                    bs.face_list, img, st);
-    dmr::launch_tet_forward(*s, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
-    DMR_HIP(hipGetLastError());
-    return 0;
+    PointState ps; FaceState fs; ImageState is;
+    auto render = [&](const BinningState& bs) {
+        dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
+                               is.last_face, is.last_tet, is.is_active};
+        dmr::launch_tet_first_intersect(*s, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
+                                        bs.face_list, img, st);
+        dmr::launch_tet_forward(*s, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
+    };
+    return run_forward(s, true, d, alloc, ctx, st, ps, fs, is, num_rendered, render);
 }
 
 int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL_ddepth, const void* point_buf,

@@ -54,10 +54,11 @@ void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offse
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
-                             hipStream_t st);
+                             uint32_t capacity, hipStream_t st);
+// nhits is read on the device (*hit_total, clamped to capacity): the launch does not wait for the host to know it
 void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, uint32_t nhits, float* vrow, float* frow,
-                              hipStream_t st);
+                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
+                              uint32_t capacity, float* vrow, float* frow, hipStream_t st);
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
                        float* dL_dvcolor, float* dL_dfopacity, float* dL_dvdepth, float* dL_dfintense,
                        hipStream_t st);

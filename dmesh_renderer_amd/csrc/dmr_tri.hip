@@ -349,7 +349,7 @@ constexpr int BWD_SLOTS = DMR_BWD_SLOTS;
 
 __global__ void __launch_bounds__(256)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits) {
+                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity) {
     constexpr int CHUNK = 64;
     static_assert(BWD_CHUNK == CHUNK, "one thread per (face, quadrant) in the transposition");
     __shared__ CovRec s_cov[CHUNK];
@@ -550,7 +550,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
                 hr.entry = begin + lo + (uint32_t)k;
                 hr.pixel = (uint32_t)((int64_t)b * HW + (int64_t)p.W * hy + hx);
                 hr.T = rec.x; hr.dL_dalpha = rec.y;
-                hits[hit_cursor + i] = hr;
+                if (hit_cursor + (uint32_t)i < capacity) hits[hit_cursor + i] = hr;  // capacity < total only while a size guess is being refuted
             }
             hit_cursor += (uint32_t)H;
             // the loop-top __syncthreads_or keeps pass k+1 from overwriting s_pool/s_pmask/s_cmask/s_hits early
@@ -572,7 +572,9 @@ constexpr int STAGE_SEGS = 16;  // segment totals staged per flush round and wav
 
 __global__ void __launch_bounds__(256)
 k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits,
-                    uint32_t nhits, float* __restrict__ vrow, float* __restrict__ frow) {
+                    const unsigned long long* __restrict__ hit_total, uint32_t capacity,
+                    float* __restrict__ vrow, float* __restrict__ frow) {
+    const uint32_t nhits = (uint32_t)min((unsigned long long)capacity, *hit_total);
     __shared__ float s_stage[4][STAGE_SEGS][28];  // 23 sums, v0, v1, v2, face, view
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t HW = (int64_t)p.H * p.W;
@@ -759,22 +761,23 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
-                             hipStream_t st) {
+                             uint32_t capacity, hipStream_t st) {
     if (r1 <= r0) return;
     TriParams p = make_params(s, gx, gy, r0, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
-    k_tri_backward_pix<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits);
+    k_tri_backward_pix<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity);
 }
 
 void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, uint32_t nhits, float* vrow, float* frow,
-                              hipStream_t st) {
-    if (nhits == 0) return;
+                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
+                              uint32_t capacity, float* vrow, float* frow, hipStream_t st) {
+    if (capacity == 0) return;
+    const uint32_t nhits = capacity;  // grid size from the host-known bound
     TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr};
     TriParams p = make_params(s, 0, 0, 0, vproj, nullptr, face_list, none);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((nhits + 255u) / 256u, 256u * 16u);
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
-    k_tri_backward_hits<<<dim3(blocks), dim3(256), 0, st>>>(p, pixrec, hits, nhits, vrow, frow);
+    k_tri_backward_hits<<<dim3(blocks), dim3(256), 0, st>>>(p, pixrec, hits, hit_total, capacity, vrow, frow);
 }
 
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,

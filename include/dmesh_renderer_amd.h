@@ -42,8 +42,9 @@ enum { DMR_BUF_POINT = 0, DMR_BUF_FACE = 1, DMR_BUF_BINNING = 2, DMR_BUF_IMAGE =
 
 /* C equivalent of the reference's four std::function<char*(size_t)> allocators
  * (rasterizer.h:14-17, render.cu:18-24): must return a device pointer to at least
- * `nbytes` bytes (256-byte aligned), or NULL on failure.  Called at most once per
- * buffer per call, from the calling thread. */
+ * `nbytes` bytes (256-byte aligned), or NULL on failure.  Called from the calling thread,
+ * normally once per buffer per call; a second request for the same buffer (larger size) replaces the
+ * first one -- it happens when a size guess taken from the previous call turned out too small. */
 typedef void* (*dmr_alloc_fn)(void* ctx, int which, size_t nbytes);
 
 typedef struct dmr_scene {

@@ -115,6 +115,32 @@ def test_band_rows_compose(oracle, hip_device):
         assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) <= GRAD_TOL
 
 
+def test_size_guess_is_refuted_and_redone(oracle, hip_device):
+    """Speculative sizing: the library sizes the binning / hit-record buffers from the previous call with the
+    same tensor shapes.  Render a small-on-screen mesh first, then the same shapes filling the screen (R and the
+    hit count grow far beyond the +25 % guess): the stages must be redone with exact sizes, results exact."""
+    from dmesh_renderer_amd import _C
+    L, n, B, H, W = 3, 14, 1, 160, 160
+    gc, gd = upstream_grads(B, H, W)
+    rs = []
+    for scale in (0.12, 1.0, 0.3, 1.0):
+        d = scenes.layered_sheets(L, n, B, H, W, seed=7)
+        d["verts"] = d["verts"] * scale
+        sc = oracle.scene_from_module_inputs(d, H, W)
+        ocolor, odepth, ost = oracle.tri_forward(sc)
+        og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+        args = c_args(d, hip_device)
+        out = _C.render_tris(*args, H, W)
+        g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7])
+        th.cuda.synchronize()
+        rs.append(out[0])
+        assert out[0] == ost.num_rendered
+        assert np.abs(out[1].cpu().numpy() - ocolor).max() <= FWD_TOL
+        for got, key in zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")):
+            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (scale, key)
+    assert rs[1] > 1.5 * rs[0], "second scene must exceed the size guess"
+
+
 def test_module_autograd(oracle, hip_device):
     """TriRenderer Module: loss.backward() routes the five gradients like the reference wrapper."""
     import dmesh_renderer_amd as dmr
