@@ -134,21 +134,25 @@ __device__ __forceinline__ V3 load_v3(const float* __restrict__ a, int id) {
     return {a[3 * id], a[3 * id + 1], a[3 * id + 2]};
 }
 
-// cuda_renderer/auxiliary.h:345-394
-__device__ __forceinline__ V3 tet_face_outward_normal(const float* __restrict__ verts, const int* __restrict__ faces,
-                                                      const int* __restrict__ tets, int face_idx, int tet_idx) {
-    V3 p0 = load_v3(verts, faces[3 * face_idx]);
-    V3 p1 = load_v3(verts, faces[3 * face_idx + 1]);
-    V3 p2 = load_v3(verts, faces[3 * face_idx + 2]);
+// cuda_renderer/auxiliary.h:345-394, split so that a march step computes the tet centre once for the
+// four faces it tests (same arithmetic per face, so results are unchanged)
+__device__ __forceinline__ V3 tet_center(const float* __restrict__ verts, const int* __restrict__ tets, int tet_idx) {
+    V3 q0 = load_v3(verts, tets[4 * tet_idx]), q1 = load_v3(verts, tets[4 * tet_idx + 1]);
+    V3 q2 = load_v3(verts, tets[4 * tet_idx + 2]), q3 = load_v3(verts, tets[4 * tet_idx + 3]);
+    return (q0 + q1 + q2 + q3) * 0.25f;
+}
+__device__ __forceinline__ V3 face_outward_normal(V3 p0, V3 p1, V3 p2, V3 center) {
     V3 n = cross(p1 - p0, p2 - p0);
     float n_norm = sqrtf(dot(n, n));
     n_norm = fmaxf(n_norm, 0.0001f);
     n = n / n_norm;
-    V3 q0 = load_v3(verts, tets[4 * tet_idx]), q1 = load_v3(verts, tets[4 * tet_idx + 1]);
-    V3 q2 = load_v3(verts, tets[4 * tet_idx + 2]), q3 = load_v3(verts, tets[4 * tet_idx + 3]);
-    V3 center = (q0 + q1 + q2 + q3) * 0.25f;
     if (dot(n, center - p0) > 0.0f) n = -n;
     return n;
+}
+__device__ __forceinline__ V3 tet_face_outward_normal(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                      const int* __restrict__ tets, int face_idx, int tet_idx) {
+    return face_outward_normal(load_v3(verts, faces[3 * face_idx]), load_v3(verts, faces[3 * face_idx + 1]),
+                               load_v3(verts, faces[3 * face_idx + 2]), tet_center(verts, tets, tet_idx));
 }
 
 // ---------------------------------------------------------------------------

@@ -112,7 +112,9 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
         cnt++;
     }
     if (cnt != 3) return false;
-    const V3 ncur = tet_face_outward_normal(p.verts, p.faces, p.tets, curr_face, curr_tet);
+    const V3 center = tet_center(p.verts, p.tets, curr_tet);
+    const V3 ncur = face_outward_normal(load_v3(p.verts, p.faces[3 * curr_face]), load_v3(p.verts, p.faces[3 * curr_face + 1]),
+                                        load_v3(p.verts, p.faces[3 * curr_face + 2]), center);
     const float dcur = dot(ncur, rd);
     if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
     int nf = -1, ncnt = 0;
@@ -121,9 +123,10 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     for (int i = 0; i < 3; i++) {
         V3 tuv;
         const int of = others[i];
-        const bool hit = ray_tri_hit(ro, rd, load_v3(p.verts, p.faces[3 * of]), load_v3(p.verts, p.faces[3 * of + 1]),
-                                     load_v3(p.verts, p.faces[3 * of + 2]), tuv);
-        const V3 n = tet_face_outward_normal(p.verts, p.faces, p.tets, of, curr_tet);
+        const V3 a0 = load_v3(p.verts, p.faces[3 * of]), a1 = load_v3(p.verts, p.faces[3 * of + 1]),
+                 a2 = load_v3(p.verts, p.faces[3 * of + 2]);
+        const bool hit = ray_tri_hit(ro, rd, a0, a1, a2, tuv);
+        const V3 n = face_outward_normal(a0, a1, a2, center);
         const float dn = dot(n, rd);
         if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) { nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; ncnt++; }
     }

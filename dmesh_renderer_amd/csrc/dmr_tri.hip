@@ -691,7 +691,7 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             const int sub = lane & 31, grp = sub >> 3, comp = sub & 7;
             for (int s0 = 0; s0 < nseg; s0 += 2) {
                 const int sg = s0 + (lane >> 5);
-                if (sg >= nseg) continue;
+                if (sg >= nseg || (p.dbg & 512)) continue;
                 const float* st = s_stage[wave][sg];
                 const int sb = __float_as_int(st[27]);
                 if (grp < 3) {
