@@ -351,18 +351,14 @@ __global__ void __launch_bounds__(256)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity) {
     constexpr int CHUNK = 64;
-    static_assert(BWD_CHUNK == CHUNK, "one thread per (face, quadrant) in the transposition");
+    static_assert(BWD_CHUNK == CHUNK, "64-bit per-pixel masks, one wave scans the 64 face counters");
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
-    __shared__ uint64_t s_cmask[CHUNK][4];          // [face][quadrant]: pixels of the quadrant that took the face this pass
-    __shared__ uint64_t s_pmask[TILE_PIX];          // [pixel]: faces handled by the pixel this pass
+    __shared__ uint32_t s_fcnt[CHUNK];              // hits per face this pass
+    __shared__ uint32_t s_fcur[CHUNK];              // claim cursor per face
+    __shared__ uint32_t s_fstart[CHUNK + 1];        // exclusive scan of s_fcnt
     __shared__ float2 s_pool[BWD_SLOTS][TILE_PIX];  // [hit ordinal from the back][pixel] = (T, dL_dalpha)
-    // s_mx (phase A hand-off) and s_hits (phase C hit list) are never live together: one buffer
-    __shared__ uint32_t s_mx_hits[4 * 4 * 64];
-    uint32_t (*s_mx)[4][64] = reinterpret_cast<uint32_t (*)[4][64]>(s_mx_hits);  // [quadrant][face block][lane]
-    uint16_t* s_hits = reinterpret_cast<uint16_t*>(s_mx_hits);  // face-major hit list of a pass: face << 8 | pixel
-    static_assert(sizeof(uint16_t) * TILE_PIX * BWD_SLOTS <= sizeof(uint32_t) * 4 * 4 * 64, "hit list fits");
-    __shared__ int s_wsum[4];
+    __shared__ uint32_t s_mx[4][4][64];             // phase A hand-off: [quadrant][face block][lane]
     __shared__ uint32_t s_max_last;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -403,6 +399,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     const float bd_dot = 0.f + (float)(1.0 * (double)dpd);
 
     if (tid == 0) s_max_last = 0;
+    if (tid < CHUNK) s_fcnt[tid] = 0u;
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_last, last_contributor);
     __syncthreads();
@@ -415,8 +412,6 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     float acr0 = 0, acr1 = 0, acr2 = 0, acrd = 0;
     float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0;
 
-    // thread identity in the transposition
-    const int fk = tid >> 2, fq = tid & 3;
 
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
     for (uint32_t ci = 0; ci < nchunks; ci++) {
@@ -496,64 +491,49 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
                     dL_dalpha += (-T_final * inv_1ma) * bd_dot;
                 }
                 s_pool[h][tid] = make_float2(T, dL_dalpha);
+                atomicAdd(&s_fcnt[k], 1u);
                 pm |= bit;
                 h++;
             }
-            s_pmask[tid] = pm;
-            // transpose: for every face of the chunk, which pixels of this quadrant took it this pass
-            if (__any(pm != 0ull)) {
-                for (int j = 0; j < n; j++) {
-                    const uint64_t bal = __ballot((pm >> j) & 1ull);
-                    if (lane == 0) s_cmask[j][wave] = bal;
+            // ---- C: face-major slots.  Integer LDS atomics run at full rate on gfx950 (4 cycles per wave
+            // instruction when conflict-free; ds_add_f32 takes ~200), so the (pixel, face) -> face-major
+            // transposition is: count per face (B did that), scan the 64 counts, then every pixel claims a
+            // slot per hit with a returning ds_add and writes its 16-byte record straight to the tile's region.
+            __syncthreads();  // all counts of this pass are in
+            if (wave == 0) {
+                const int c = (lane < n) ? (int)s_fcnt[lane] : 0;
+                int incl = c;
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    const int o = __shfl_up(incl, dlt, 64);
+                    if (lane >= dlt) incl += o;
                 }
-            } else if (lane < n) {
-                s_cmask[lane][wave] = 0ull;
+                s_fstart[lane] = (uint32_t)(incl - c);
+                if (lane == 63) s_fstart[64] = (uint32_t)incl;
+                s_fcnt[lane] = 0u;  // clean for the next pass
+                s_fcur[lane] = 0u;
             }
             __syncthreads();
-
-            // ---- C: face-major hit list of this pass.  Thread (fk, fq) owns the hits of face fk in quadrant fq;
-            // an exclusive block scan of the counts gives every hit a slot, consecutive slots = same face.
-            uint64_t cm = (fk < n) ? s_cmask[fk][fq] : 0ull;
-            const int cnt = __popcll(cm);
-            int incl = cnt;
-#pragma unroll
-            for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                const int o = __shfl_up(incl, dlt, 64);
-                if (lane >= dlt) incl += o;
+            const uint32_t Hp = s_fstart[64];
+            {
+                uint64_t m = pm;
+                int hh = 0;
+                const uint32_t pixel = (uint32_t)bpix;
+                while (m != 0ull) {
+                    const int k = 63 - __clzll((long long)m);
+                    m &= ~(1ull << k);
+                    const uint32_t slot = s_fstart[k] + atomicAdd(&s_fcur[k], 1u);
+                    const float2 rec = s_pool[hh][tid];
+                    hh++;
+                    HitRecord hr;
+                    hr.entry = begin + lo + (uint32_t)k;
+                    hr.pixel = pixel;
+                    hr.T = rec.x; hr.dL_dalpha = rec.y;
+                    if (hit_cursor + slot < capacity) hits[hit_cursor + slot] = hr;  // capacity < total only while a size guess is being refuted
+                }
             }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            int hbase = incl - cnt;
-            int H = 0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const int ws = s_wsum[w];
-                if (w < wave) hbase += ws;
-                H += ws;
-            }
-            while (cm != 0ull) {
-                const int l = __ffsll((long long)cm) - 1;
-                cm &= cm - 1ull;
-                s_hits[hbase++] = (uint16_t)((fk << 8) | (fq * 64 + l));
-            }
-            __syncthreads();
-            // write the records (coalesced 16-byte stores)
-            for (int i = tid; i < H; i += 256) {
-                const uint32_t desc = s_hits[i];
-                const int k = (int)(desc >> 8), pp = (int)(desc & 0xffu);
-                const uint64_t pmk = s_pmask[pp];
-                const int ord = __popcll(k < 63 ? (pmk >> (k + 1)) : 0ull);  // hits of that pixel behind face k
-                const float2 rec = s_pool[ord][pp];
-                const int q = pp >> 6, l = pp & 63;
-                const int hx = tx * TILE + (q & 1) * 8 + (l & 7), hy = ty * TILE + (q >> 1) * 8 + (l >> 3);
-                HitRecord hr;
-                hr.entry = begin + lo + (uint32_t)k;
-                hr.pixel = (uint32_t)((int64_t)b * HW + (int64_t)p.W * hy + hx);
-                hr.T = rec.x; hr.dL_dalpha = rec.y;
-                if (hit_cursor + (uint32_t)i < capacity) hits[hit_cursor + i] = hr;  // capacity < total only while a size guess is being refuted
-            }
-            hit_cursor += (uint32_t)H;
-            // the loop-top __syncthreads_or keeps pass k+1 from overwriting s_pool/s_pmask/s_cmask/s_hits early
+            hit_cursor += Hp;
+            __syncthreads();  // claims done before wave 0 clears / rescans the counters in the next pass
         }
     }
 }
