@@ -163,7 +163,7 @@ __device__ __forceinline__ V3 tet_face_outward_normal(const float* __restrict__ 
 //     s_i(x, y) = s0_i + bx_i * (x - x0) + by_i * (y - y0)      (mod 2^32, as int32 wraps, Q7)
 // for a tile whose first pixel is (x0, y0).  `ok` is false for zero-area faces.
 // ---------------------------------------------------------------------------
-struct EdgeSetup { int32_t s0[3], bx[3], by[3]; bool ok; int qmask; };
+struct EdgeSetup { int32_t s0[3], bx[3], by[3]; bool ok; int x0, x1, y0, y1; };  // box: tile-local pixels, inclusive
 
 __device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int y0) {
     const float sub = 16.0f;
@@ -187,22 +187,20 @@ __device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int
         e.bx[i] = (int32_t)(0u - 16u * cy[i]);
         e.by[i] = (int32_t)(16u * cx[i]);
     }
-    // Quadrant mask.  A pixel centre (16x+8, 16y+8) can only pass the three edge tests if it lies inside the
+    // Pixel box.  A pixel centre (16x+8, 16y+8) can only pass the three edge tests if it lies inside the
     // closed box of the snapped vertices -- provided nothing wrapped: with every vertex within 2^15
-    // sub-pixels (2048 px) of the tile origin all products stay below 2^31.  Otherwise keep all quadrants.
+    // sub-pixels (2048 px) of the tile origin all products stay below 2^31.  Otherwise the whole tile.
     const int32_t X[3] = {(int32_t)x1, (int32_t)x2, (int32_t)x3}, Y[3] = {(int32_t)y1, (int32_t)y2, (int32_t)y3};
     const int32_t ox = 16 * x0 + 8, oy = 16 * y0 + 8;  // centre of the tile's first pixel
     bool near = true;
 #pragma unroll
     for (int i = 0; i < 3; i++) near = near && abs(X[i] - ox) < (1 << 15) && abs(Y[i] - oy) < (1 << 15) && abs(X[i]) < (1 << 29) && abs(Y[i]) < (1 << 29);
-    e.qmask = 15;
+    e.x0 = 0; e.x1 = TILE - 1; e.y0 = 0; e.y1 = TILE - 1;
     if (near) {
         const int32_t minx = min(min(X[0], X[1]), X[2]) - ox, maxx = max(max(X[0], X[1]), X[2]) - ox;
         const int32_t miny = min(min(Y[0], Y[1]), Y[2]) - oy, maxy = max(max(Y[0], Y[1]), Y[2]) - oy;
-        // quadrant columns 0..7 have centres 0..112 (sub-pixels from ox), columns 8..15 have 128..240
-        const bool cx0 = minx <= 112 && maxx >= 0, cx1 = minx <= 240 && maxx >= 128;
-        const bool cy0 = miny <= 112 && maxy >= 0, cy1 = miny <= 240 && maxy >= 128;
-        e.qmask = (cx0 && cy0 ? 1 : 0) | (cx1 && cy0 ? 2 : 0) | (cx0 && cy1 ? 4 : 0) | (cx1 && cy1 ? 8 : 0);
+        e.x0 = max(0, (minx + 15) >> 4); e.x1 = min(TILE - 1, maxx >> 4);   // ceil / floor of the centre index
+        e.y0 = max(0, (miny + 15) >> 4); e.y1 = min(TILE - 1, maxy >> 4);
     }
     return e;
 }

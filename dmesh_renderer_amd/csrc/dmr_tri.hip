@@ -38,17 +38,15 @@ constexpr int BWD_CHUNK = 64;
 // s_i(x, y) = s0[i] + bx[i] * (x - x0) + by[i] * (y - y0) (mod 2^32), inside iff all three < 0.
 // A zero-area face (in_tri returns false, auxiliary.h:201-202) and the padding entries of a
 // partially filled 32-face word are stored as the all-zero record, which covers nothing.
-// flags bit 8 (COV_BIG): some bx/by does not fit a signed 24-bit operand (an edge longer than 32768 px),
-// so the chunk must use full 32-bit multiplies instead of v_mad_i32_i24.
-// flags bits 0-3: which 8x8 quadrants of the tile the face's fixed-point bounding box can cover at all
-// (bit q = quadrant (q & 1, q >> 1)); 15 whenever the face is not "near" the tile, i.e. when int32
-// wrap-around (Q7) could make the edge functions claim pixels outside the box.
+// flags: bit 16 = the record covers something at all (0 for zero-area faces and padding); bits 0-15 =
+// the tile-local pixel box x0 | x1 << 4 | y0 << 8 | y1 << 12 that can contain covered pixel centres
+// (the whole tile when int32 wrap-around, Q7, could make the edge functions claim pixels outside it).
 struct alignas(16) CovRec {
     int32_t s0[3]; int32_t flags;
     int32_t bx[3]; int32_t pad0;
     int32_t by[3]; int32_t pad1;
 };
-constexpr int COV_BIG = 0x100;
+constexpr int COV_VALID = 0x10000;
 static_assert(sizeof(CovRec) == 48, "CovRec");
 
 // T = ray_o - p0, E1 = p1 - p0, E2 = p2 - p0, Q = cross(T, E1): the pixel-independent part of
@@ -70,8 +68,7 @@ struct TriParams {
     uint32_t* tile_hits; const uint32_t* hit_offset;
 };
 
-// returns cov.big
-__device__ __forceinline__ int stage_face(const TriParams& p, int b, int face, int x0, int y0, V3 ray_o,
+__device__ __forceinline__ void stage_face(const TriParams& p, int b, int face, int x0, int y0, V3 ray_o,
                                           CovRec& cov, ShadeRec& sh, int* vid) {
     const int v0 = p.faces[3 * face], v1 = p.faces[3 * face + 1], v2 = p.faces[3 * face + 2];
     const float4 a0 = p.vproj[(int64_t)b * p.P + v0];
@@ -80,13 +77,11 @@ __device__ __forceinline__ int stage_face(const TriParams& p, int b, int face, i
     const V3 p0 = load_v3(p.verts, v0), p1 = load_v3(p.verts, v1), p2 = load_v3(p.verts, v2);
     const V3 c0 = load_v3(p.verts_color, v0), c1 = load_v3(p.verts_color, v1), c2 = load_v3(p.verts_color, v2);
     EdgeSetup e = edge_setup({a0.x, a0.y}, {a1.x, a1.y}, {a2.x, a2.y}, x0, y0);
-    int big = 0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        cov.s0[i] = e.ok ? e.s0[i] : 0; cov.bx[i] = e.ok ? e.bx[i] : 0; cov.by[i] = e.ok ? e.by[i] : 0;
-        big |= (cov.bx[i] != ((cov.bx[i] << 8) >> 8)) | (cov.by[i] != ((cov.by[i] << 8) >> 8));
-    }
-    cov.flags = e.ok ? ((big ? COV_BIG : 0) | e.qmask) : 0; cov.pad0 = 0; cov.pad1 = 0;
+    for (int i = 0; i < 3; i++) { cov.s0[i] = e.s0[i]; cov.bx[i] = e.bx[i]; cov.by[i] = e.by[i]; }
+    const bool some = e.ok && e.x0 <= e.x1 && e.y0 <= e.y1;
+    cov.flags = some ? (COV_VALID | e.x0 | (e.x1 << 4) | (e.y0 << 8) | (e.y1 << 12)) : 0;
+    cov.pad0 = 0; cov.pad1 = 0;
     const V3 T = ray_o - p0, E1 = p1 - p0, E2 = p2 - p0;
     const V3 Q = cross(T, E1);
     sh.T[0] = T.x; sh.T[1] = T.y; sh.T[2] = T.z;
@@ -100,7 +95,6 @@ __device__ __forceinline__ int stage_face(const TriParams& p, int b, int face, i
     sh.opacity = p.faces_opacity[face];
     sh.intense = p.faces_intense[(int64_t)b * p.F + face];
     if (vid) { vid[0] = v0; vid[1] = v1; vid[2] = v2; vid[3] = face; }
-    return big;
 }
 
 __device__ __forceinline__ void stage_null(CovRec& cov) {
@@ -108,52 +102,33 @@ __device__ __forceinline__ void stage_null(CovRec& cov) {
     q[0] = make_int4(0, 0, 0, 0); q[1] = make_int4(0, 0, 0, 0); q[2] = make_int4(0, 0, 0, 0);
 }
 
-// Phase A.  Reading a face's 36-byte coverage record is a wave-wide LDS broadcast that occupies
-// the CU's single LDS pipe for 12 cycles whoever asks, so letting all four waves of the tile read
-// every record made the kernel LDS-issue bound (measured: 157 of 232 us at C4).  Instead the chunk
-// is split into four blocks of NB consecutive faces and wave w evaluates block w for ALL 256 pixels:
-// each lane covers its pixel position in the four 8x8 quadrants (edge values of the other three
-// quadrants are one v_lshl_add_u32 away: + 8*bx, + 8*by).  mq[q] bit i = face (block w, i) covers
-// this lane's pixel of quadrant q.  The masks then change hands through LDS (s_mx).
-template <bool BIG, int NB>
-__device__ __forceinline__ void coverage_block(const CovRec* __restrict__ cov, int count, int lane, uint32_t mq[4]) {
-    const int lx = lane & 7, ly = lane >> 3;
-    mq[0] = mq[1] = mq[2] = mq[3] = 0;
-    if (count <= 0) return;
-    // software pipeline: the record of face j+1 is in flight while face j is evaluated
-    const int4* __restrict__ q = reinterpret_cast<const int4*>(cov);
-    int4 n0 = q[0], n1 = q[1], n2 = q[2];
-    for (int j = 0; j < count; j++) {
-        const int4 c0 = n0, c1 = n1, c2 = n2;  // {s0[3], flags}, {bx[3], -}, {by[3], -}
-        const int jn = min(j + 1, count - 1);
-        n0 = q[3 * jn]; n1 = q[3 * jn + 1]; n2 = q[3 * jn + 2];
-        // wave-uniform: quadrants the face's box misses cost one scalar branch instead of ~8 VALU
-        const int qm = __builtin_amdgcn_readfirstlane(c0.w) & 15;
-        if (qm == 0) continue;
-        const int s0[3] = {c0.x, c0.y, c0.z}, bx[3] = {c1.x, c1.y, c1.z}, by[3] = {c2.x, c2.y, c2.z};
-        uint32_t e[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            if (BIG) e[i] = (uint32_t)s0[i] + (uint32_t)bx[i] * (uint32_t)lx + (uint32_t)by[i] * (uint32_t)ly;
-            else e[i] = (uint32_t)(__mul24(by[i], ly) + (__mul24(bx[i], lx) + s0[i]));
-        }
-        const uint32_t bit = 1u << j;
-        if (qm & 1) {
-            const uint32_t t = e[0] & e[1] & e[2];
-            mq[0] |= (uint32_t)((int32_t)t >> 31) & bit;
-        }
-        if (qm & 2) {
-            const uint32_t t = (e[0] + ((uint32_t)bx[0] << 3)) & (e[1] + ((uint32_t)bx[1] << 3)) & (e[2] + ((uint32_t)bx[2] << 3));
-            mq[1] |= (uint32_t)((int32_t)t >> 31) & bit;
-        }
-        if (qm & 4) {
-            const uint32_t t = (e[0] + ((uint32_t)by[0] << 3)) & (e[1] + ((uint32_t)by[1] << 3)) & (e[2] + ((uint32_t)by[2] << 3));
-            mq[2] |= (uint32_t)((int32_t)t >> 31) & bit;
-        }
-        if (qm & 8) {
-            const uint32_t t = (e[0] + ((uint32_t)bx[0] << 3) + ((uint32_t)by[0] << 3)) & (e[1] + ((uint32_t)bx[1] << 3) + ((uint32_t)by[1] << 3))
-                             & (e[2] + ((uint32_t)bx[2] << 3) + ((uint32_t)by[2] << 3));
-            mq[3] |= (uint32_t)((int32_t)t >> 31) & bit;
+// Phase A, face-parallel.  256 / CHUNK threads rasterise one staged face each (interleaved rows of its pixel
+// box): the three fixed-point edge functions are stepped incrementally (+bx per pixel) and every covered
+// pixel centre gets the face's bit OR-ed into that pixel's mask word in LDS.  ds_or_b32 runs at full rate on
+// gfx950 (scripts/micro/lds_atomics.hip), so a 6x6-pixel triangle costs ~150 lane-instructions instead of
+// the ~1900 lane-slots of testing all 256 pixels of the tile against it (the earlier pixel-parallel
+// versions: every wave reading every record was LDS-issue bound, 157 of 232 us at C4; one wave per
+// 32-face block for all four quadrants with quadrant culling, 45-65 us).
+template <int CHUNK>
+__device__ __forceinline__ void rasterize_faces(const CovRec* __restrict__ cov, int n, int tid,
+                                                uint32_t (*__restrict__ pm)[CHUNK / 32]) {
+    constexpr int TPF = 256 / CHUNK;  // threads per face
+    const int j = tid / TPF, sub = tid % TPF;
+    if (j >= n) return;
+    const CovRec& c = cov[j];
+    const int fl = c.flags;
+    if (!(fl & COV_VALID)) return;
+    const int x0 = fl & 15, x1 = (fl >> 4) & 15, y0 = (fl >> 8) & 15, y1 = (fl >> 12) & 15;
+    const uint32_t bit = 1u << (j & 31);
+    const int word = j >> 5;
+    const uint32_t bx0 = (uint32_t)c.bx[0], bx1 = (uint32_t)c.bx[1], bx2 = (uint32_t)c.bx[2];
+    for (int y = y0 + sub; y <= y1; y += TPF) {
+        uint32_t e0 = (uint32_t)c.s0[0] + (uint32_t)c.by[0] * (uint32_t)y + bx0 * (uint32_t)x0;
+        uint32_t e1 = (uint32_t)c.s0[1] + (uint32_t)c.by[1] * (uint32_t)y + bx1 * (uint32_t)x0;
+        uint32_t e2 = (uint32_t)c.s0[2] + (uint32_t)c.by[2] * (uint32_t)y + bx2 * (uint32_t)x0;
+        for (int x = x0; x <= x1; x++) {
+            if ((int32_t)(e0 & e1 & e2) < 0) atomicOr(&pm[y * TILE + x][word], bit);
+            e0 += bx0; e1 += bx1; e2 += bx2;
         }
     }
 }
@@ -165,7 +140,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     static_assert(WORDS == 4, "one 32-face block per wave");
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
-    __shared__ uint32_t s_mx[4][4][64];  // [quadrant][face block = evaluating wave][lane]
+    __shared__ uint32_t s_pm[TILE_PIX][WORDS];  // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
@@ -189,28 +164,21 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     for (uint32_t base = begin; base < end; base += CHUNK) {
         if (__syncthreads_and(done)) break;  // also fences LDS reuse
         const int n = (int)min((uint32_t)CHUNK, end - base);
-        int big = 0;
-        if (tid < n && !(p.dbg & 32)) big = stage_face(p, b, (int)p.face_list[base + tid], tx * TILE, ty * TILE, view_o,
-                                      s_cov[tid], s_shade[tid], nullptr);
-        else if (tid < ((n + 31) & ~31)) stage_null(s_cov[tid]);
-        const bool any_big = __syncthreads_or(big);
-
-        // A: this wave evaluates faces [32*wave, 32*wave+32) of the chunk for the whole tile
-        {
-            uint32_t mq[4];
-            const int cnt = (p.dbg & 16) ? 0 : min(32, max(0, n - 32 * wave));
-            if (any_big) coverage_block<true, 32>(s_cov + 32 * wave, cnt, lane, mq);
-            else coverage_block<false, 32>(s_cov + 32 * wave, cnt, lane, mq);
-#pragma unroll
-            for (int q = 0; q < 4; q++) s_mx[q][wave][lane] = mq[q];
-        }
+        if (tid < n && !(p.dbg & 32)) stage_face(p, b, (int)p.face_list[base + tid], tx * TILE, ty * TILE, view_o,
+                                                 s_cov[tid], s_shade[tid], nullptr);
+        else if (tid < CHUNK) stage_null(s_cov[tid]);
+        *reinterpret_cast<uint4*>(&s_pm[tid][0]) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        if (!(p.dbg & 16)) rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // A
         __syncthreads();
         uint32_t m[WORDS];
-#pragma unroll
-        for (int w = 0; w < WORDS; w++) {
-            m[w] = s_mx[wave][w][lane];
-            if (done || (p.dbg & 8)) m[w] = 0;
+        {
+            const uint4 mm = *reinterpret_cast<const uint4*>(&s_pm[ly * TILE + lx][0]);
+            m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
         }
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) if (done || (p.dbg & 8)) m[w] = 0;
+        if (__all(done)) continue;  // wave-uniform
         while (true) {
             int w = -1; uint32_t mw = 0;
 #pragma unroll
@@ -358,7 +326,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     __shared__ uint32_t s_fcur[CHUNK];              // claim cursor per face
     __shared__ uint32_t s_fstart[CHUNK + 1];        // exclusive scan of s_fcnt
     __shared__ float2 s_pool[BWD_SLOTS][TILE_PIX];  // [hit ordinal from the back][pixel] = (T, dL_dalpha)
-    __shared__ uint32_t s_mx[4][4][64];             // phase A hand-off: [quadrant][face block][lane]
+    __shared__ uint32_t s_pm[TILE_PIX][CHUNK / 32]; // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
     __shared__ uint32_t s_max_last;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -419,27 +387,18 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         const uint32_t lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
         const int n = (int)(hi - lo);
         __syncthreads();  // previous chunk is done with the LDS records
-        int big = 0;
         if (tid < n)
-            big = stage_face(p, b, (int)p.face_list[begin + lo + tid], tx * TILE, ty * TILE, view_o,
-                             s_cov[tid], s_shade[tid], nullptr);
-        else if (tid < ((n + 31) & ~31)) stage_null(s_cov[tid]);
-        const bool any_big = __syncthreads_or(big);
-
-        // ---- A: wave w evaluates faces [16w, 16w+16) for the whole tile; masks change hands via s_mx
-        {
-            uint32_t mq[4];
-            const int cnt = min(16, max(0, n - 16 * wave));
-            if (any_big) coverage_block<true, 16>(s_cov + 16 * wave, cnt, lane, mq);
-            else coverage_block<false, 16>(s_cov + 16 * wave, cnt, lane, mq);
-#pragma unroll
-            for (int q = 0; q < 4; q++) s_mx[q][wave][lane] = mq[q];
-        }
+            stage_face(p, b, (int)p.face_list[begin + lo + tid], tx * TILE, ty * TILE, view_o,
+                       s_cov[tid], s_shade[tid], nullptr);
+        else if (tid < CHUNK) stage_null(s_cov[tid]);
+        *reinterpret_cast<uint2*>(&s_pm[tid][0]) = make_uint2(0u, 0u);
+        __syncthreads();
+        rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // ---- A
         __syncthreads();
         uint64_t rem;
         {
-            rem = (uint64_t)s_mx[wave][0][lane] | ((uint64_t)s_mx[wave][1][lane] << 16)
-                | ((uint64_t)s_mx[wave][2][lane] << 32) | ((uint64_t)s_mx[wave][3][lane] << 48);
+            const uint2 mm = *reinterpret_cast<const uint2*>(&s_pm[ly * TILE + lx][0]);
+            rem = (uint64_t)mm.x | ((uint64_t)mm.y << 32);
             const int64_t lim = (int64_t)last_contributor - (int64_t)lo;  // keep positions < last_contributor
             if (lim <= 0) rem = 0;
             else if (lim < 64) rem &= (1ull << lim) - 1ull;
