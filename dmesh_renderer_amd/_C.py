@@ -153,8 +153,12 @@ def render_tris(background, verts, faces, verts_color, faces_opacity, mv_mats, p
     with th.cuda.device(dev):
         call = _Call(dev, background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                      inv_proj_mats, verts_depth, faces_intense, image_height, image_width, rows=rows)
-        color = th.zeros((call.B, NUM_CHANNELS, call.H, call.W), dtype=th.float32, device=dev)
-        depth = th.zeros((call.B, 1, call.H, call.W), dtype=th.float32, device=dev)
+        # the kernels write every pixel of the rendered rows; zero-fill (render.cu:88-89) is only needed when
+        # nothing is launched (P == 0 / F == 0, render.cu:105) or when a band leaves rows untouched
+        full = tuple(rows) == (0, 0) and call.P > 0 and call.F > 0
+        alloc_img = th.empty if full else th.zeros
+        color = alloc_img((call.B, NUM_CHANNELS, call.H, call.W), dtype=th.float32, device=dev)
+        depth = alloc_img((call.B, 1, call.H, call.W), dtype=th.float32, device=dev)
         rendered = C.c_int(0)
         rc = lib.dmr_tri_forward(C.byref(call.scene), color.data_ptr(), depth.data_ptr(), call.alloc, None,
                                  call.stream(), C.byref(rendered))

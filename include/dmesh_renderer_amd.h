@@ -69,8 +69,9 @@ typedef struct dmr_scene {
     int32_t row_begin, row_end;
 } dmr_scene;
 
-/* out_color [B,3,H,W], out_depth [B,1,H,W] must be zero-initialised by the caller
- * (render.cu:88-89).  *num_rendered receives R = sum of tiles touched. */
+/* out_color [B,3,H,W], out_depth [B,1,H,W]: every pixel of the rendered tile rows is written; the caller
+ * zero-initialises them (render.cu:88-89) when a band leaves rows untouched or when P == 0 / F == 0
+ * (nothing is launched, render.cu:105).  *num_rendered receives R = sum of tiles touched. */
 int dmr_tri_forward(const dmr_scene* scene, float* out_color, float* out_depth,
                     dmr_alloc_fn alloc, void* alloc_ctx, void* stream, int* num_rendered);
 
