@@ -257,34 +257,32 @@ constexpr int DPP_ROW_SHR = 0x110;      // + n, n = 1..15
 constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of the next row
 constexpr int DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
 
-// One level of the segmented inclusive scan over the 23 components: lanes whose source lane carries the
-// same face key add the source's partial sum.  Hand-scheduled: hipcc turns the obvious
-// "g += same ? dpp(g) : 0" into mov + nop + mov_dpp + cndmask + add per value; here it is
-// v_cndmask_b32_dpp (select 0 / shifted value on VCC = "different key") + v_add_f32 -- two VALU per value.
-// Lanes without a valid source read 0 (bound_ctrl:0); rows excluded by row_mask never write `t`, which
-// is zeroed once per level.
-#define DMR_SEG2(N, DPP) "v_cndmask_b32_dpp %[t], %[g" #N "], %[z], vcc " DPP "\n\tv_add_f32 %[g" #N "], %[g" #N "], %[t]\n\t"
+// One level of the segmented inclusive scan over the 23 components: g += m * g[source lane], m = 1.0 where the
+// source lane carries the same list entry, else 0.0.  One v_fmac_f32_dpp per value (scripts/micro/valu_rates.hip:
+// 4.8 SIMD cycles, against 9.1 for the v_cndmask_b32_dpp + v_add_f32 pair this replaces; v_add_f32_dpp under an
+// EXEC mask cannot be used because DPP does not read EXEC-disabled source lanes).  Lanes without a valid source
+// read 0 (bound_ctrl:0); rows excluded by row_mask are not written.  A non-finite value (quirk Q12) would turn
+// 0 * inf into NaN for the neighbouring segment: such lanes are taken out of the scan by the caller.
+#define DMR_SEG1(N, DPP) "v_fmac_f32_dpp %[g" #N "], %[g" #N "], %[m] " DPP "\n\t"
 #define DMR_SEG_LEVEL(DPP)                                                                                     \
-    asm volatile("s_mov_b64 vcc, %[ns]\n\tv_mov_b32 %[t], 0\n\ts_nop 1\n\t"                                     \
-                 DMR_SEG2(0, DPP) DMR_SEG2(1, DPP) DMR_SEG2(2, DPP) DMR_SEG2(3, DPP) DMR_SEG2(4, DPP) DMR_SEG2(5, DPP)  \
-                 DMR_SEG2(6, DPP) DMR_SEG2(7, DPP) DMR_SEG2(8, DPP) DMR_SEG2(9, DPP) DMR_SEG2(10, DPP) DMR_SEG2(11, DPP) \
-                 DMR_SEG2(12, DPP) DMR_SEG2(13, DPP) DMR_SEG2(14, DPP) DMR_SEG2(15, DPP) DMR_SEG2(16, DPP)          \
-                 DMR_SEG2(17, DPP) DMR_SEG2(18, DPP) DMR_SEG2(19, DPP) DMR_SEG2(20, DPP) DMR_SEG2(21, DPP)          \
-                 DMR_SEG2(22, DPP)                                                                             \
-                 : [t] "=&v"(t), [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]),  \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 DMR_SEG1(0, DPP) DMR_SEG1(1, DPP) DMR_SEG1(2, DPP) DMR_SEG1(3, DPP) DMR_SEG1(4, DPP) DMR_SEG1(5, DPP)  \
+                 DMR_SEG1(6, DPP) DMR_SEG1(7, DPP) DMR_SEG1(8, DPP) DMR_SEG1(9, DPP) DMR_SEG1(10, DPP) DMR_SEG1(11, DPP) \
+                 DMR_SEG1(12, DPP) DMR_SEG1(13, DPP) DMR_SEG1(14, DPP) DMR_SEG1(15, DPP) DMR_SEG1(16, DPP)          \
+                 DMR_SEG1(17, DPP) DMR_SEG1(18, DPP) DMR_SEG1(19, DPP) DMR_SEG1(20, DPP) DMR_SEG1(21, DPP)          \
+                 DMR_SEG1(22, DPP)                                                                             \
+                 : [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]),              \
                    [g5] "+v"(g[5]), [g6] "+v"(g[6]), [g7] "+v"(g[7]), [g8] "+v"(g[8]), [g9] "+v"(g[9]),             \
                    [g10] "+v"(g[10]), [g11] "+v"(g[11]), [g12] "+v"(g[12]), [g13] "+v"(g[13]), [g14] "+v"(g[14]),   \
                    [g15] "+v"(g[15]), [g16] "+v"(g[16]), [g17] "+v"(g[17]), [g18] "+v"(g[18]), [g19] "+v"(g[19]),   \
                    [g20] "+v"(g[20]), [g21] "+v"(g[21]), [g22] "+v"(g[22])                                      \
-                 : [z] "v"(0.0f), [ns] "s"(ns)                                                                 \
-                 : "vcc")
+                 : [m] "v"(m))
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
     static_assert(NACC == 23, "the asm lists 23 registers");
     const int ko = dpp_i<CTRL, ROW_MASK>((int)0x80000000, k);
-    const uint64_t ns = __ballot(ko != k);  // lanes that must NOT add (different face, or no source lane)
-    float t;
+    const float m = (ko == k) ? 1.0f : 0.0f;  // keys are list entries (< 2^31) or negative per-lane ids: never 0x80000000
     if (CTRL == DPP_ROW_SHR + 1) DMR_SEG_LEVEL("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
     else if (CTRL == DPP_ROW_SHR + 2) DMR_SEG_LEVEL("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
     else if (CTRL == DPP_ROW_SHR + 4) DMR_SEG_LEVEL("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
@@ -507,18 +505,129 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
 // with PACKED global atomics: 3 vertex rows + 1 face row per segment (4 memory-side requests) instead of
 // the reference's 23 global atomics per (pixel, face) (backward.cu:389-418).
 // ---------------------------------------------------------------------------
-constexpr int STAGE_SEGS = 16;  // segment totals staged per flush round and wave
+// From here to k_tri_backward_hits' end the compiler may contract a*b+c to FMA: gradients are checked to 1e-4
+// and the reference's own sums are unordered float atomics.  F3 is this block's vector type (the V3 helpers of
+// dmr_device.hpp were compiled under -ffp-contract=off and keep that when inlined).  The forward and everything
+// that decides an index stay exact.
+#ifndef DMR_HITS_NOCONTRACT
+#pragma clang fp contract(fast)
+#endif
+namespace fm {
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ F3 operator*(float b, F3 a) { return {b * a.x, b * a.y, b * a.z}; }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ F3 load3(const float* __restrict__ a, int id) { return {a[3 * id], a[3 * id + 1], a[3 * id + 2]}; }
+}  // namespace fm
 
+constexpr int STAGE_SEGS = 16;   // segment totals staged per wave before a flush: 16 x (3 vertex rows + 1 face row) = 64 refs
+constexpr int STAGE_ROW = 28;    // 23 sums, v0, v1, v2, face, view
+constexpr int DEDUP_SLOTS = 128;
+
+struct HitsLds {
+    float stage[4][STAGE_SEGS][STAGE_ROW];
+    int owner[4][DEDUP_SLOTS];
+    int list[4][64];
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Flush of the n <= 16 staged segment totals of one wave.  Global float atomics execute at the memory side at
+// ~20 G 64-byte requests/s chip-wide whatever they carry (MI355X_MICROARCH.md, "Global float atomics"): with one
+// request per (segment, row) -- 3 vertex rows + 1 face row -- this kernel was bound by exactly that (0.195 ms with
+// the atomics, 0.110 ms without, 0.195 ms with one dword per row).  Consecutive list entries of a tile are
+// neighbouring faces of one surface (the list is depth sorted), so their vertex rows repeat: every (segment, row)
+// reference finds the first reference to the same row in the window through a small wave-private hash (plain LDS
+// store + read-back elects a slot's owner, linear probing on a foreign owner), followers add their values onto the
+// leader's staged row (ds_add_f32, a few lanes), and only leaders go out -- 8 lanes per row, 8 rows per instruction.
+__device__ __forceinline__ void flush_staged(const TriParams& p, HitsLds& L, int wave, int lane, int n,
+                                             float* __restrict__ vrow, float* __restrict__ frow) {
+    wave_lds_sync();  // the staged rows are visible to the whole wave
+    const int sg = lane >> 2, w = lane & 3;
+    const bool active = sg < n;
+    float* row = L.stage[wave][active ? sg : 0];
+    const int sb = __float_as_int(row[27]);
+    // row id: vertex rows first, face rows behind them (B * P and B * F are < 2^31 each)
+    const uint32_t rid = w < 3 ? (uint32_t)sb * (uint32_t)p.P + (uint32_t)__float_as_int(row[23 + w])
+                               : (uint32_t)p.B * (uint32_t)p.P + (uint32_t)sb * (uint32_t)p.F + (uint32_t)__float_as_int(row[26]);
+    volatile int* owner = L.owner[wave];
+    uint32_t slot = (rid * 2654435761u) >> 25;  // 128 slots
+    int leader = lane;
+    bool pending = active;
+    while (__ballot(pending)) {
+        if (pending) owner[slot] = lane;
+        wave_lds_sync();
+        const int wl = pending ? owner[slot] : lane;
+        const uint32_t rw = (uint32_t)__shfl((int)rid, wl, 64);
+        if (pending) {
+            if (rw == rid) { leader = wl; pending = false; }
+            else slot = (slot + 1u) & (uint32_t)(DEDUP_SLOTS - 1);
+        }
+        wave_lds_sync();
+    }
+    if (active && leader != lane) {  // follower: fold into the leader's staged row
+        float* tgt = L.stage[wave][leader >> 2];
+        const int lw = leader & 3;
+        if (w < 3) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                atomicAdd(&tgt[3 * lw + c], row[3 * w + c]);
+                atomicAdd(&tgt[9 + 3 * lw + c], row[9 + 3 * w + c]);
+            }
+            atomicAdd(&tgt[18 + lw], row[18 + w]);
+        } else {
+            atomicAdd(&tgt[21], row[21]);
+            atomicAdd(&tgt[22], row[22]);
+        }
+    }
+    const uint64_t lmask = __ballot(active && leader == lane);
+    const int nrows = __popcll(lmask);
+    if (active && leader == lane) L.list[wave][__popcll(lmask & ((1ull << lane) - 1ull))] = lane;
+    wave_lds_sync();
+    const int grp = lane >> 3, comp = lane & 7;
+    for (int i0 = 0; i0 < nrows; i0 += 8) {
+        const int idx = i0 + grp;
+        if (idx >= nrows || (p.dbg & 512)) continue;
+        const int src = L.list[wave][idx];
+        const float* st = L.stage[wave][src >> 2];
+        const int sw = src & 3, vb = __float_as_int(st[27]);
+        if (sw < 3) {
+            if (comp == 7) continue;
+            const int ai = comp < 3 ? sw * 3 + comp : (comp < 6 ? 9 + sw * 3 + (comp - 3) : 18 + sw);
+            atomicAdd(&vrow[((int64_t)vb * p.P + __float_as_int(st[23 + sw])) * VROW + comp], st[ai]);
+        } else if (comp < 2) {
+            atomicAdd(&frow[((int64_t)vb * p.F + __float_as_int(st[26])) * FROW + comp], st[21 + comp]);
+        }
+    }
+    wave_lds_sync();  // the stage area may be refilled
+}
+
+#ifdef DMR_HITS_WAVES
+__attribute__((amdgpu_waves_per_eu(DMR_HITS_WAVES, DMR_HITS_WAVES)))
+#endif
 __global__ void __launch_bounds__(256)
 k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits,
                     const unsigned long long* __restrict__ hit_total, uint32_t capacity,
                     float* __restrict__ vrow, float* __restrict__ frow) {
     const uint32_t nhits = (uint32_t)min((unsigned long long)capacity, *hit_total);
-    __shared__ float s_stage[4][STAGE_SEGS][28];  // 23 sums, v0, v1, v2, face, view
+    __shared__ HitsLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t HW = (int64_t)p.H * p.W;
-    const uint32_t stride = gridDim.x * 256u;
-    for (uint32_t base = blockIdx.x * 256u + wave * 64u; base < nhits; base += stride) {
+    // every wave owns a contiguous range of hit records, so that the dedup window of flush_staged sees
+    // neighbouring list entries
+    const uint32_t nwaves = gridDim.x * 4u, niter = (nhits + 63u) / 64u;
+    const uint32_t per_wave = (niter + nwaves - 1u) / nwaves;
+    const uint32_t it0 = min(niter, (blockIdx.x * 4u + (uint32_t)wave) * per_wave), it1 = min(niter, it0 + per_wave);
+    int staged = 0;
+    for (uint32_t it = it0; it < it1; it++) {
+        const uint32_t base = it * 64u;
         const uint32_t hi_idx = base + lane;
         const bool valid = hi_idx < nhits;
         int k = -1 - lane;  // invalid lanes: unique keys
@@ -527,77 +636,94 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
 #pragma unroll
         for (int c = 0; c < NACC; c++) g[c] = 0.f;
         if (valid) {
+            using namespace fm;
             const HitRecord hr = hits[hi_idx];
             k = (int)hr.entry;
             face = (int)p.face_list[hr.entry];
             b = (int)(hr.pixel / (uint32_t)HW);
             v0 = p.faces[3 * face]; v1 = p.faces[3 * face + 1]; v2 = p.faces[3 * face + 2];
             const float4 pr0 = pixrec[2 * (int64_t)hr.pixel], pr1 = pixrec[2 * (int64_t)hr.pixel + 1];
-            const V3 d = {pr0.x, pr0.y, pr0.z};
-            const float gdp = pr0.w, g0 = pr1.x, g1 = pr1.y, g2 = pr1.z;
-            const V3 p0 = load_v3(p.verts, v0), p1 = load_v3(p.verts, v1), p2 = load_v3(p.verts, v2);
-            const V3 cc0 = load_v3(p.verts_color, v0), cc1 = load_v3(p.verts_color, v1), cc2 = load_v3(p.verts_color, v2);
+            const float alpha = p.faces_opacity[face], intense = p.faces_intense[(int64_t)b * p.F + face];
+            const F3 cc0 = load3(p.verts_color, v0), cc1 = load3(p.verts_color, v1), cc2 = load3(p.verts_color, v2);
             const float fd0 = p.vproj[(int64_t)b * p.P + v0].w, fd1 = p.vproj[(int64_t)b * p.P + v1].w,
                         fd2 = p.vproj[(int64_t)b * p.P + v2].w;
-            const float alpha = p.faces_opacity[face], intense = p.faces_intense[(int64_t)b * p.F + face];
-            const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
-            const V3 Tv = view_o - p0, E1 = p1 - p0, E2 = p2 - p0;
-            const V3 Q = cross(Tv, E1);
-            const float c00 = cc0.x, c01 = cc0.y, c02 = cc0.z, c10 = cc1.x, c11 = cc1.y, c12 = cc1.z;
-            const float c20 = cc2.x, c21 = cc2.y, c22 = cc2.z;
-            const float Th = hr.T;
-
-            const V3 Pv = cross(d, E2);
-            const float denom = dot(Pv, E1);
-            const float inv_denom = fast_rcp(denom);
-            const float nu = dot(Pv, Tv);
-            const float iu = nu * inv_denom;
-            const float iv = dot(Q, d) * inv_denom;
+            // forward quantities of this (pixel, face) pair (backward.cu:206-243).  Exact arithmetic (the V3 helpers
+            // are not contracted): the clamp region `code` selects a piecewise-constant Jacobian, so (u, v) must land
+            // on the same side of the region borders as in the forward.
+            float iu, iv, denom, nu;
+            F3 d, Tv, E1, E2, Q, Pv;
+            {
+                const V3 xd = {pr0.x, pr0.y, pr0.z};
+                const V3 xp0 = load_v3(p.verts, v0), xp1 = load_v3(p.verts, v1), xp2 = load_v3(p.verts, v2);
+                const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
+                const V3 xT = view_o - xp0, xE1 = xp1 - xp0, xE2 = xp2 - xp0;
+                const V3 xQ = dmr::cross(xT, xE1), xP = dmr::cross(xd, xE2);
+                denom = dmr::dot(xP, xE1);
+                const float inv_denom = fast_rcp(denom);
+                nu = dmr::dot(xP, xT);
+                iu = nu * inv_denom;
+                iv = dmr::dot(xQ, xd) * inv_denom;
+                d = {xd.x, xd.y, xd.z}; Tv = {xT.x, xT.y, xT.z}; E1 = {xE1.x, xE1.y, xE1.z}; E2 = {xE2.x, xE2.y, xE2.z};
+                Q = {xQ.x, xQ.y, xQ.z}; Pv = {xP.x, xP.y, xP.z};
+            }
             float iuc, ivc; int code;
             clamp_bary_uv(iu, iv, iuc, ivc, code);
             const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
-            const float dic0 = g0 * alpha * Th, dic1 = g1 * alpha * Th, dic2 = g2 * alpha * Th;
-            const float did = gdp * alpha * Th;
-
-            float dL_di0 = 0, dL_di1 = 0, dL_di2 = 0, dfint = 0;
-            dL_di0 += c00 * dic0 * intense; dL_di1 += c10 * dic0 * intense; dL_di2 += c20 * dic0 * intense;
-            dfint += (i0 * c00 + i1 * c10 + i2 * c20) * dic0;
-            dL_di0 += c01 * dic1 * intense; dL_di1 += c11 * dic1 * intense; dL_di2 += c21 * dic1 * intense;
-            dfint += (i0 * c01 + i1 * c11 + i2 * c21) * dic1;
-            dL_di0 += c02 * dic2 * intense; dL_di1 += c12 * dic2 * intense; dL_di2 += c22 * dic2 * intense;
-            dfint += (i0 * c02 + i1 * c12 + i2 * c22) * dic2;
-            dL_di0 += fd0 * did; dL_di1 += fd1 * did; dL_di2 += fd2 * did;
-
+            // dL/dcolor and dL/ddepth of the pair (backward.cu:254-275), the face intensity folded in once
+            const float aT = alpha * hr.T;
+            const float dic0 = pr1.x * aT, dic1 = pr1.y * aT, dic2 = pr1.z * aT, did = pr0.w * aT;
+            const float dii0 = dic0 * intense, dii1 = dic1 * intense, dii2 = dic2 * intense;
+            // dL/d(barycentric weights) (backward.cu:313-330)
+            const float dL_di0 = cc0.x * dii0 + cc0.y * dii1 + cc0.z * dii2 + fd0 * did;
+            const float dL_di1 = cc1.x * dii0 + cc1.y * dii1 + cc1.z * dii2 + fd1 * did;
+            const float dL_di2 = cc2.x * dii0 + cc2.y * dii1 + cc2.z * dii2 + fd2 * did;
+            const float dfint = (i0 * cc0.x + i1 * cc1.x + i2 * cc2.x) * dic0 + (i0 * cc0.y + i1 * cc1.y + i2 * cc2.y) * dic1
+                              + (i0 * cc0.z + i1 * cc1.z + i2 * cc2.z) * dic2;
+            // through the clamp (i0 = 1 - uc - vc, i1 = uc, i2 = vc; Jacobian of auxiliary.h:374-400)
             float duc_du, duc_dv, dvc_du, dvc_dv;
             clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
-            const float di0_diu = -1.f * duc_du + -1.f * dvc_du, di0_div = -1.f * duc_dv + -1.f * dvc_dv;
-            const float di1_diu = 1.f * duc_du + 0.f * dvc_du, di1_div = 1.f * duc_dv + 0.f * dvc_dv;
-            const float di2_diu = 0.f * duc_du + 1.f * dvc_du, di2_div = 0.f * duc_dv + 1.f * dvc_dv;
-            const float dL_diu = dL_di0 * di0_diu + dL_di1 * di1_diu + dL_di2 * di2_diu;
-            const float dL_div = dL_di0 * di0_div + dL_di1 * di1_div + dL_di2 * di2_div;
-
-            // ray_tri_intersection_grad (auxiliary.h:288-333), Q11/Q12 kept
-            const float dsq = denom, den2 = dsq * dsq, dinv = fast_rcp(den2);
-            const float w0 = nu, w1 = dsq, w2 = dot(Q, E2);
-            const V3 du_dE1 = (-1.0f * Pv * w0) * dinv;
-            const V3 du_dE2 = (cross(Tv, d) * w1 - w0 * cross(E1, d)) * dinv;
-            const V3 du_dT = (Pv * w1) * dinv;
-            const V3 dv_dE1 = ((cross(E2, Tv) * w1) - (w2 * Pv)) * dinv;
-            const V3 dv_dE2 = ((Q * w1) - (w2 * cross(E1, d))) * dinv;
-            const V3 dv_dT = cross(E1, E2) * w1 * dinv;
-            const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
-            const V3 dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
-            const V3 dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
-            const V3 dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
+            const float e1 = dL_di1 - dL_di0, e2 = dL_di2 - dL_di0;
+            const float dL_diu = e1 * duc_du + e2 * dvc_du;
+            const float dL_div = e1 * duc_dv + e2 * dvc_dv;
+            // ray_tri_intersection_grad (auxiliary.h:288-333; Q11: the "v" numerator is t's, Q12: no clamp of
+            // denom^2), regrouped: with a = dL_diu / denom^2, b = dL_div / denom^2, w0 = P.T, w1 = denom, w2 = Q.E2
+            //   dL/dE1 = s3 P + s2 (E2 x T),  dL/dE2 = s1 (T x d) + s3 (E1 x d) + s2 Q,  dL/dT = s1 P + s2 (E1 x E2)
+            //   s1 = a w1, s2 = b w1, s3 = -(a w0 + b w2);  p1 <- dL/dE1, p2 <- dL/dE2, p0 <- -(dL/dE1 + dL/dE2 + dL/dT)
+            const float dinv = fast_rcp(denom * denom);
+            const float ga = dL_diu * dinv, gb = dL_div * dinv;
+            const float s1 = ga * denom, s2 = gb * denom, s3 = -(ga * nu + gb * dot(Q, E2));
+            const F3 dp1 = s3 * Pv + s2 * cross(E2, Tv);
+            const F3 dp2 = s1 * cross(Tv, d) + s3 * cross(E1, d) + s2 * Q;
+            const F3 dT = s1 * Pv + s2 * cross(E1, E2);
+            const F3 dp0 = -(dp1 + dp2 + dT);
 
             g[0] = dp0.x; g[1] = dp0.y; g[2] = dp0.z;
             g[3] = dp1.x; g[4] = dp1.y; g[5] = dp1.z;
             g[6] = dp2.x; g[7] = dp2.y; g[8] = dp2.z;
-            g[9] = i0 * dic0 * intense; g[10] = i0 * dic1 * intense; g[11] = i0 * dic2 * intense;
-            g[12] = i1 * dic0 * intense; g[13] = i1 * dic1 * intense; g[14] = i1 * dic2 * intense;
-            g[15] = i2 * dic0 * intense; g[16] = i2 * dic1 * intense; g[17] = i2 * dic2 * intense;
+            g[9] = i0 * dii0; g[10] = i0 * dii1; g[11] = i0 * dii2;
+            g[12] = i1 * dii0; g[13] = i1 * dii1; g[14] = i1 * dii2;
+            g[15] = i2 * dii0; g[16] = i2 * dii1; g[17] = i2 * dii2;
             g[18] = i0 * did; g[19] = i1 * did; g[20] = i2 * did;
             g[21] = hr.dL_dalpha; g[22] = dfint;
+
+            // The scan below multiplies neighbours' partial sums by 0/1 masks, so a non-finite value must not enter
+            // it (0 * inf = NaN would leak into the next list entry).  Such a pair (degenerate face, Q12; opacity
+            // exactly 1 behind it) adds its values with plain atomics, as the reference does for every pair.
+            const float chk = (dinv * 0.f) + (aT * 0.f) + (hr.dL_dalpha * 0.f);
+            if (!(chk == 0.f)) {
+                float* r0 = vrow + ((int64_t)b * p.P + v0) * VROW; float* r1 = vrow + ((int64_t)b * p.P + v1) * VROW;
+                float* r2 = vrow + ((int64_t)b * p.P + v2) * VROW; float* rf = frow + ((int64_t)b * p.F + face) * FROW;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    atomicAdd(r0 + c, g[c]); atomicAdd(r1 + c, g[3 + c]); atomicAdd(r2 + c, g[6 + c]);
+                    atomicAdd(r0 + 3 + c, g[9 + c]); atomicAdd(r1 + 3 + c, g[12 + c]); atomicAdd(r2 + 3 + c, g[15 + c]);
+                }
+                atomicAdd(r0 + 6, g[18]); atomicAdd(r1 + 6, g[19]); atomicAdd(r2 + 6, g[20]);
+                atomicAdd(rf, g[21]); atomicAdd(rf + 1, g[22]);
+#pragma unroll
+                for (int c = 0; c < NACC; c++) g[c] = 0.f;
+                k = -1 - lane;
+            }
         }
         // segmented inclusive scan over the wave (hits of one entry are consecutive lanes): four row-local
         // DPP levels, then the two row-broadcast levels of the classic wave scan
@@ -608,44 +734,29 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         seg_scan_level<DPP_ROW_BCAST15, 0xA>(k, g);
         seg_scan_level<DPP_ROW_BCAST31, 0xC>(k, g);
 
-        // segment tails hold the totals; stage them (wave-private LDS) and flush with packed atomics
+        // segment tails hold the totals: append them to the wave's stage area, flush whenever it is full
         const int kn = __shfl_down(k, 1, 64);
         const bool tail = valid && (lane == 63 || kn != k);
         const uint64_t tmask = __ballot(tail);
         const int ntail = __popcll(tmask);
         const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-        for (int r0 = 0; r0 < ntail; r0 += STAGE_SEGS) {
-            if (tail && rank >= r0 && rank < r0 + STAGE_SEGS) {
-                float* st = s_stage[wave][rank - r0];
+        for (int t0 = 0; t0 < ntail;) {
+            const int take = min(STAGE_SEGS - staged, ntail - t0);
+            if (tail && rank >= t0 && rank < t0 + take) {
+                float* st = L.stage[wave][staged + rank - t0];
 #pragma unroll
                 for (int c = 0; c < NACC; c++) st[c] = g[c];
                 st[23] = __int_as_float(v0); st[24] = __int_as_float(v1); st[25] = __int_as_float(v2);
                 st[26] = __int_as_float(face); st[27] = __int_as_float(b);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nseg = min(STAGE_SEGS, ntail - r0);
-            // 32 lanes per segment = 3 vertex rows x 8 + face row x 8 (2 used); 2 segments per sweep
-            const int sub = lane & 31, grp = sub >> 3, comp = sub & 7;
-            for (int s0 = 0; s0 < nseg; s0 += 2) {
-                const int sg = s0 + (lane >> 5);
-                if (sg >= nseg || (p.dbg & 512)) continue;
-                const float* st = s_stage[wave][sg];
-                const int sb = __float_as_int(st[27]);
-                if (grp < 3) {
-                    if (comp == 7) continue;
-                    const int ai = comp < 3 ? grp * 3 + comp : (comp < 6 ? 9 + grp * 3 + (comp - 3) : 18 + grp);
-                    atomicAdd(&vrow[((int64_t)sb * p.P + __float_as_int(st[23 + grp])) * VROW + comp], st[ai]);
-                } else if (comp < 2) {
-                    atomicAdd(&frow[((int64_t)sb * p.F + __float_as_int(st[26])) * FROW + comp], st[21 + comp]);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            staged += take; t0 += take;
+            if (staged == STAGE_SEGS) { flush_staged(p, L, wave, lane, staged, vrow, frow); staged = 0; }
         }
     }
+    if (staged) flush_staged(p, L, wave, lane, staged, vrow, frow);
 }
+
+#pragma clang fp contract(off)
 
 // packed accumulators -> the five gradient tensors of render.cu:166-171
 __global__ void __launch_bounds__(256)
