@@ -37,6 +37,19 @@ def _f32(t: th.Tensor, name: str) -> th.Tensor:
     return t.contiguous()
 
 
+def _mat(t: th.Tensor, name: str):
+    """[B,4,4] matrix -> (tensor to keep alive, transposed-storage flag).  render.cu:117-120 makes the
+    `.transpose(1, 2)` views of the wrapper contiguous with four copy kernels per call; the library reads
+    that storage in place instead (dmr_scene.mats_transposed)."""
+    if t.dtype != th.float32:
+        _err(f"expected scalar type Float but found {t.dtype} ({name})")
+    if t.is_contiguous():
+        return t, 0
+    if t.dim() == 3 and t.transpose(1, 2).is_contiguous():
+        return t, 1
+    return t.contiguous(), 0
+
+
 def _i32(t: th.Tensor, name: str) -> th.Tensor:
     if t.dtype != th.int32:
         _err(f"expected scalar type Int but found {t.dtype} ({name})")
@@ -93,11 +106,12 @@ class _Call:
     def __init__(self, dev, bg, verts, faces, verts_color, faces_opacity, mv, proj, inv_mv, inv_proj, verts_depth,
                  faces_intense, H, W, tets=None, face_tets=None, tet_faces=None, seed=0, rows=(0, 0)):
         self.dev = dev
+        (mv, f0), (proj, f1), (inv_mv, f2), (inv_proj, f3) = (_mat(mv, "mv_mats"), _mat(proj, "proj_mats"),
+                                                             _mat(inv_mv, "inv_mv_mats"), _mat(inv_proj, "inv_proj_mats"))
         k = self.keep = {
             "bg": _f32(bg, "background"), "verts": _f32(verts, "verts"), "faces": _i32(faces, "faces"),
             "vc": _f32(verts_color, "verts_color"), "fo": _f32(faces_opacity, "faces_opacity"),
-            "mv": _f32(mv, "mv_mats"), "proj": _f32(proj, "proj_mats"),
-            "imv": _f32(inv_mv, "inv_mv_mats"), "iproj": _f32(inv_proj, "inv_proj_mats"),
+            "mv": mv, "proj": proj, "imv": inv_mv, "iproj": inv_proj,
             "vd": _f32(verts_depth, "verts_depth"), "fi": _f32(faces_intense, "faces_intense"),
         }
         if bg.numel() < NUM_CHANNELS:
@@ -114,7 +128,8 @@ class _Call:
         self.scene = _lib.Scene(self.B, self.P, self.F, self.T, self.W, self.H,
                                 p("bg"), p("verts"), p("faces"), p("vc"), p("fo"),
                                 p("mv"), p("proj"), p("imv"), p("iproj"), p("vd"), p("fi"),
-                                p("tets"), p("ft"), p("tf"), int(seed), int(rows[0]), int(rows[1]))
+                                p("tets"), p("ft"), p("tf"), int(seed), int(rows[0]), int(rows[1]),
+                                f0 | (f1 << 1) | (f2 << 2) | (f3 << 3))
         self.buffers: Dict[int, th.Tensor] = {}
 
         def alloc(_ctx, which, nbytes):

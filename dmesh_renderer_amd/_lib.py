@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdmesh_renderer_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 BUF_POINT, BUF_FACE, BUF_BINNING, BUF_IMAGE, BUF_WORK = range(5)
 NUM_STAGES = 12
@@ -31,6 +31,7 @@ class Scene(C.Structure):
         ("verts_depth", C.c_void_p), ("faces_intense", C.c_void_p),
         ("tets", C.c_void_p), ("face_tets", C.c_void_p), ("tet_faces", C.c_void_p),
         ("ray_random_seed", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
+        ("mats_transposed", C.c_int32),
     ]
 
 

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -51,6 +52,7 @@ struct ImageState {
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
     uint32_t* tile_hits; uint32_t* hit_offset; unsigned long long* hit_total;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
+    float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
 };
 struct BinningState { uint64_t* keys; uint32_t* face_list; };
 
@@ -62,8 +64,9 @@ size_t carve_face(void* b, size_t BF, bool tet, FaceState& s) {
     s.tiles_touched = c.take<uint32_t>(BF);
     return c.off;
 }
-size_t carve_image(void* b, size_t ntiles, size_t npix, bool tet, ImageState& s) {
+size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, ImageState& s) {
     Carver c(b);
+    s.mats = c.take<float>(64 * B);
     s.tile_count = c.take<uint32_t>(ntiles); s.tile_offset = c.take<uint32_t>(ntiles + 1);
     s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(1);
     s.final_T = c.take<float>(npix); s.final_prev_T = c.take<float>(npix); s.n_contrib = c.take<uint32_t>(npix);
@@ -87,6 +90,15 @@ size_t carve_binning(void* b, size_t R, BinningState& s) {
 }
 
 struct Dims { int gx, gy, r0, r1, ntiles; size_t BP, BF, npix; };
+
+// The scene as every kernel behind k_project_verts sees it: matrices in contract layout, read from the image buffer.
+dmr_scene canonical(const dmr_scene* s, const float* mats) {
+    dmr_scene c = *s;
+    const size_t n = 16 * (size_t)s->B;
+    c.mv_mats = mats; c.proj_mats = mats + n; c.inv_mv_mats = mats + 2 * n; c.inv_proj_mats = mats + 3 * n;
+    c.mats_transposed = 0;
+    return c;
+}
 
 int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     if (!s) return fail("null scene");
@@ -146,18 +158,18 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     PointState tp; FaceState tf; ImageState ti;
     void* pb = alloc(ctx, DMR_BUF_POINT, carve_point(nullptr, d.BP, tp));
     void* fb = alloc(ctx, DMR_BUF_FACE, carve_face(nullptr, d.BF, tet, tf));
-    void* ib = alloc(ctx, DMR_BUF_IMAGE, carve_image(nullptr, (size_t)d.ntiles, d.npix, tet, ti));
+    void* ib = alloc(ctx, DMR_BUF_IMAGE, carve_image(nullptr, (size_t)s->B, (size_t)d.ntiles, d.npix, tet, ti));
     if (!pb || !fb || !ib) return fail("scratch allocation failed");
     carve_point(pb, d.BP, ps);
     carve_face(fb, d.BF, tet, fs);
-    carve_image(ib, (size_t)d.ntiles, d.npix, tet, is);
+    carve_image(ib, (size_t)s->B, (size_t)d.ntiles, d.npix, tet, is);
     SizeRead* sr = size_read();
     if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
     int* host_R = reinterpret_cast<int*>(sr->slot);
 
     auto front = [&]() -> int {
         DMR_HIP(hipMemsetAsync(is.tile_count, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
-        dmr::launch_project_verts(*s, ps.vproj, st);
+        dmr::launch_project_verts(*s, ps.vproj, is.mats, st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
         dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, st);
@@ -289,7 +301,8 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
         dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
-        dmr::launch_tri_forward(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
+        const dmr_scene sc = canonical(s, is.mats);
+        dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
                                 out_depth, st);
     };
     return run_forward(s, false, d, alloc, ctx, st, ps, fs, is, num_rendered, render);
@@ -318,7 +331,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     PointState ps; FaceState fs; ImageState is; BinningState bs;
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
     carve_face(const_cast<void*>(face_buf), d.BF, false, fs);
-    carve_image(const_cast<void*>(image_buf), (size_t)d.ntiles, d.npix, false, is);
+    carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, false, is);
     carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, bs);
 
     // The forward counted the blended (pixel, face) pairs per tile; their scan places every tile's hit
@@ -339,10 +352,16 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
         DMR_HIP(hipMemsetAsync(work, 0, vbytes + fbytes, st));
         dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
-        dmr::launch_tri_backward_pix(*s, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img,
+        const dmr_scene sc = canonical(s, is.mats);
+        // One band = the whole flattened (view, tile row) range.  Splitting it into bands whose hit-parallel kernel
+        // runs on a second stream while the next band's per-pixel kernel computes (atomic unit and SIMDs busy at
+        // the same time) was measured and lost: 0.56 ms per step with 1 band, 0.64 with 2, 0.70 with 4 (C4) --
+        // cross-stream event waits cost more than the overlap gains.
+        const int nq = s->B * d.gy;
+        dmr::launch_tri_backward_pix(sc, d.gx, d.gy, d.r0, d.r1, 0, nq, ps.vproj, is.tile_offset, bs.face_list, img,
                                      dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity, st);
-        dmr::launch_tri_backward_hits(*s, ps.vproj, bs.face_list, pixrec, hits, is.hit_total, (uint32_t)capacity,
-                                      vrow, frow, st);
+        dmr::launch_tri_backward_hits(sc, ps.vproj, bs.face_list, pixrec, hits, is.hit_offset,
+                                      is.hit_offset + (size_t)nq * d.gx, (uint32_t)capacity, (uint32_t)capacity, vrow, frow, st);
         dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
         return 0;
     };
@@ -385,9 +404,10 @@ int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, floa
     auto render = [&](const BinningState& bs) {
         dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
                                is.last_face, is.last_tet, is.is_active};
-        dmr::launch_tet_first_intersect(*s, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
+        const dmr_scene sc = canonical(s, is.mats);
+        dmr::launch_tet_first_intersect(sc, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
                                         bs.face_list, img, st);
-        dmr::launch_tet_forward(*s, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
+        dmr::launch_tet_forward(sc, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
     };
     return run_forward(s, true, d, alloc, ctx, st, ps, fs, is, num_rendered, render);
 }
@@ -403,10 +423,11 @@ int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     if (s->P == 0 || s->F == 0) return 0;
     if (!image_buf) return fail("null scratch buffer");
     ImageState is;
-    carve_image(const_cast<void*>(image_buf), (size_t)d.ntiles, d.npix, true, is);
+    carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, true, is);
     dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
                            is.last_face, is.last_tet, is.is_active};
-    dmr::launch_tet_backward(*s, d.gx, d.gy, d.r0, d.r1, img, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, st);
+    const dmr_scene sc = canonical(s, is.mats);
+    dmr::launch_tet_backward(sc, d.gx, d.gy, d.r0, d.r1, img, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, st);
     DMR_HIP(hipGetLastError());
     return 0;
 }
@@ -438,7 +459,7 @@ int64_t dmr_export(const dmr_scene* s, int is_tet, int num_rendered, const char*
     PointState ps; FaceState fs; ImageState is; BinningState bs;
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
     carve_face(const_cast<void*>(face_buf), d.BF, is_tet != 0, fs);
-    carve_image(const_cast<void*>(image_buf), (size_t)d.ntiles, d.npix, is_tet != 0, is);
+    carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, is_tet != 0, is);
     carve_binning(const_cast<void*>(binning_buf), (size_t)std::max(0, num_rendered), bs);
     const std::string n(name);
     auto plain = [&](const void* src, size_t bytes) -> int64_t {

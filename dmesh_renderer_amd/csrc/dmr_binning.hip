@@ -25,15 +25,34 @@ namespace dmr {
 // 1. per (view, vertex): pixel coordinates, NDC z and the per-view depth attribute packed
 //    into one 16-byte record so later stages gather a vertex with a single dwordx4 load.
 // ---------------------------------------------------------------------------
+// Element k of a [16] column-major matrix whose 4x4 block may be stored transposed (dmr_scene.mats_transposed).
+__device__ __forceinline__ float mat_at(const float* __restrict__ m, int k, bool transposed) {
+    return m[transposed ? 4 * (k & 3) + (k >> 2) : k];
+}
+
+// Also writes the four matrices in contract layout to `mats` ([mv | proj | inv_mv | inv_proj], [B,16] each) in the
+// image buffer: every later kernel of the forward and the whole backward read them from there.
 __global__ void __launch_bounds__(256)
 k_project_verts(int B, int P, const float* __restrict__ verts, const float* __restrict__ mv_mats,
-                const float* __restrict__ proj_mats, const float* __restrict__ verts_depth,
-                int W, int H, float4* __restrict__ vproj) {
+                const float* __restrict__ proj_mats, const float* __restrict__ inv_mv_mats,
+                const float* __restrict__ inv_proj_mats, int transposed, const float* __restrict__ verts_depth,
+                int W, int H, float4* __restrict__ vproj, float* __restrict__ mats) {
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 64 * B; i += 256) {
+            const int m = i / (16 * B), r = i % (16 * B);
+            const float* src = m == 0 ? mv_mats : (m == 1 ? proj_mats : (m == 2 ? inv_mv_mats : inv_proj_mats));
+            mats[i] = mat_at(src + 16 * (r >> 4), r & 15, (transposed >> m) & 1);
+        }
+    }
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)B * P) return;
     const int b = (int)(idx / P), p = (int)(idx % P);
-    const float* mv = mv_mats + 16 * b;
-    const float* pr = proj_mats + 16 * b;
+    float mv[16], pr[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mv[k] = mat_at(mv_mats + 16 * b, k, transposed & 1);
+        pr[k] = mat_at(proj_mats + 16 * b, k, (transposed >> 1) & 1);
+    }
     V3 pv = xform4x3(load_v3(verts, p), mv);
     V4 pc = xform4x4(pv, pr);
     float p_w = (float)(1.0 / (double)clamp_w(pc.w));  // double divide (forward.cu:38)
@@ -293,7 +312,7 @@ k_scatter_faces(int B, int F, int gx, int gy, const uint2* __restrict__ face_rec
 //    no-ops, so any n works without padding storage.  n <= SORT_LDS_KEYS runs in LDS;
 //    longer segments run the same network in place in global memory.
 // ---------------------------------------------------------------------------
-constexpr int SORT_LDS_KEYS = 4096;  // 32 KiB
+constexpr int SORT_LDS_KEYS = 2048;  // 16 KiB: 8 workgroups per CU
 constexpr uint32_t RANK_SORT_MAX = 512;
 
 template <class Ptr>
@@ -325,11 +344,32 @@ __device__ __forceinline__ void bitonic_pass(Ptr a, uint32_t n, uint32_t npow2, 
     }
 }
 
+// Rank sort of one short segment (n <= RANK_SORT_MAX): keys are unique, so the number of smaller keys is the
+// output slot.  Lane l holds keys l, l + 64, ... (K per lane); wave w streams quarter w of the n keys as LDS
+// broadcasts (one ds_read_b64 serves K compares) and adds its partial ranks into s_rank with integer LDS atomics.
+template <int K>
+__device__ __forceinline__ void rank_quarter(const uint64_t* __restrict__ sk, uint32_t n, uint32_t lane, uint32_t j0,
+                                             uint32_t j1, uint32_t* __restrict__ s_rank) {
+    uint64_t k[K]; uint32_t r[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) { const uint32_t e = lane + 64u * q; k[q] = e < n ? sk[e] : ~0ull; r[q] = 0u; }
+#pragma unroll 8
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint64_t kj = sk[j];
+#pragma unroll
+        for (int q = 0; q < K; q++) r[q] += kj < k[q] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < K; q++)
+        if (lane + 64u * q < n && r[q]) atomicAdd(&s_rank[lane + 64u * q], r[q]);
+}
+
 __global__ void __launch_bounds__(256)
 k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ keys,
              uint32_t* __restrict__ face_list) {
     __shared__ uint64_t s_keys[SORT_LDS_KEYS];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_rank[RANK_SORT_MAX];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // grid-stride over tiles: most tiles of a frame are empty, a workgroup launch per tile costs more than the sort
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
@@ -339,27 +379,28 @@ k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, uint64_t
     uint32_t npow2 = 1;
     while (npow2 < n) npow2 <<= 1;
     if (n <= RANK_SORT_MAX) {
-        // Short segments (the common case: C4 averages 315 entries per busy tile): rank sort.  Keys are
-        // unique, so the number of smaller keys IS the output slot; every thread streams all n keys as
-        // LDS broadcasts -- no barriers, no dependent steps (the 45-step bitonic network was latency bound).
+        // Short segments (the common case: C4 averages 315 entries per busy tile).  The first version gave every
+        // thread one or two keys and had it loop over all n keys: 4 n LDS reads and 8 n compares per tile.  Here
+        // n reads and K n compares per tile, split four ways.
         for (uint32_t i = tid; i < n; i += 256) s_keys[i] = keys[begin + i];
+        for (uint32_t i = tid; i < n; i += 256) s_rank[i] = 0u;
         __syncthreads();
-        const uint32_t e0 = tid, e1 = tid + 256;
-        const uint64_t k0 = e0 < n ? s_keys[e0] : ~0ull, k1 = e1 < n ? s_keys[e1] : ~0ull;
-        uint32_t r0 = 0, r1 = 0;
-        if (n <= 256) {
-#pragma unroll 8
-            for (uint32_t j = 0; j < n; j++) r0 += s_keys[j] < k0 ? 1u : 0u;
-        } else {
-#pragma unroll 8
-            for (uint32_t j = 0; j < n; j++) { const uint64_t kj = s_keys[j]; r0 += kj < k0 ? 1u : 0u; r1 += kj < k1 ? 1u : 0u; }
-        }
-        if (e0 < n) { keys[begin + r0] = k0; face_list[begin + r0] = (uint32_t)k0; }
-        if (e1 < n) { keys[begin + r1] = k1; face_list[begin + r1] = (uint32_t)k1; }
+        const uint32_t per = (n + 3u) / 4u, j0 = min(n, wave * per), j1 = min(n, j0 + per);
+        const uint32_t kk = (n + 63u) / 64u;  // keys per lane, rounded up to an instantiated count
+        if (kk <= 1) rank_quarter<1>(s_keys, n, lane, j0, j1, s_rank);
+        else if (kk <= 2) rank_quarter<2>(s_keys, n, lane, j0, j1, s_rank);
+        else if (kk <= 3) rank_quarter<3>(s_keys, n, lane, j0, j1, s_rank);
+        else if (kk <= 4) rank_quarter<4>(s_keys, n, lane, j0, j1, s_rank);
+        else if (kk <= 6) rank_quarter<6>(s_keys, n, lane, j0, j1, s_rank);
+        else if (kk <= 8) rank_quarter<8>(s_keys, n, lane, j0, j1, s_rank);
+        else if (kk <= 12) rank_quarter<12>(s_keys, n, lane, j0, j1, s_rank);
+        else rank_quarter<16>(s_keys, n, lane, j0, j1, s_rank);
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) face_list[begin + s_rank[i]] = (uint32_t)s_keys[i];  // nothing reads the sorted keys
     } else if (n <= SORT_LDS_KEYS) {
         for (uint32_t i = tid; i < n; i += 256) s_keys[i] = keys[begin + i];
         __syncthreads();
-        if (n > 1) bitonic_pass(s_keys, n, npow2, tid, 256, false);
+        bitonic_pass(s_keys, n, npow2, tid, 256, false);
         for (uint32_t i = tid; i < n; i += 256) {
             uint64_t k = s_keys[i];
             keys[begin + i] = k;
@@ -376,12 +417,12 @@ k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, uint64_t
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
-void launch_project_verts(const dmr_scene& s, float4* vproj, hipStream_t st) {
+void launch_project_verts(const dmr_scene& s, float4* vproj, float* mats, hipStream_t st) {
     const int64_t n = (int64_t)s.B * s.P;
-    if (n == 0) return;
     StageScope t(DMR_STAGE_PROJECT, st);
-    k_project_verts<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
-        s.B, s.P, s.verts, s.mv_mats, s.proj_mats, s.verts_depth, s.W, s.H, vproj);
+    k_project_verts<<<dim3((unsigned)std::max<int64_t>(1, (n + 255) / 256)), dim3(256), 0, st>>>(
+        s.B, s.P, s.verts, s.mv_mats, s.proj_mats, s.inv_mv_mats, s.inv_proj_mats, s.mats_transposed, s.verts_depth,
+        s.W, s.H, vproj, mats);
 }
 
 void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int gx, int gy, int r0, int r1,
@@ -442,7 +483,7 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, hipStream_t st) {
     if (ntiles == 0) return;
     StageScope t(DMR_STAGE_SORT, st);
-    k_sort_tiles<<<dim3((unsigned)std::min(ntiles, 256 * 5)), dim3(256), 0, st>>>((uint32_t)ntiles, tile_offset, keys, face_list);
+    k_sort_tiles<<<dim3((unsigned)std::min(ntiles, 256 * 64)), dim3(256), 0, st>>>((uint32_t)ntiles, tile_offset, keys, face_list);
 }
 
 }  // namespace dmr

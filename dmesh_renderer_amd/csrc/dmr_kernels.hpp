@@ -25,7 +25,7 @@ struct StageScope {
 };
 
 // ---- binning (dmr_binning.hip)
-void launch_project_verts(const dmr_scene& s, float4* vproj, hipStream_t st);
+void launch_project_verts(const dmr_scene& s, float4* vproj, float* mats, hipStream_t st);
 void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int gx, int gy, int r0, int r1,
                         uint2* face_rect, float* key_depth, float* max_depth, uint32_t* tiles_touched,
                         uint32_t* tile_count, hipStream_t st);
@@ -51,14 +51,17 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
                         float* out_color, float* out_depth, hipStream_t st);
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
                       hipStream_t st);
-void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
+// [q0, q1): band of the flattened (view, tile row) index; rows outside [r0, r1) of a view are skipped
+void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, int q0, int q1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
                              uint32_t capacity, hipStream_t st);
-// nhits is read on the device (*hit_total, clamped to capacity): the launch does not wait for the host to know it
+// the record range [*range_begin, *range_end) is read on the device (clamped to capacity): the launch does not wait
+// for the host to know it; `expected` only sizes the grid
 void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
-                              uint32_t capacity, float* vrow, float* frow, hipStream_t st);
+                              const float4* pixrec, const HitRecord* hits, const uint32_t* range_begin,
+                              const uint32_t* range_end, uint32_t capacity, uint32_t expected, float* vrow, float* frow,
+                              hipStream_t st);
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
                        float* dL_dvcolor, float* dL_dfopacity, float* dL_dvdepth, float* dL_dfintense,
                        hipStream_t st);

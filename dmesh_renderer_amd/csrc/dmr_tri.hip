@@ -315,7 +315,7 @@ constexpr int BWD_SLOTS = DMR_BWD_SLOTS;
 
 __global__ void __launch_bounds__(256)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity) {
+                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity, int q0, int r1) {
     constexpr int CHUNK = 64;
     static_assert(BWD_CHUNK == CHUNK, "64-bit per-pixel masks, one wave scans the 64 face counters");
     __shared__ CovRec s_cov[CHUNK];
@@ -328,7 +328,10 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     __shared__ uint32_t s_max_last;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
+    // blockIdx.y walks the flattened (view, tile row) index from q0: a band of the backward (see dmr_api.hip)
+    const int q = q0 + (int)blockIdx.y;
+    const int tx = blockIdx.x, ty = q % p.gy, b = q / p.gy;
+    if (ty < p.r0 || ty >= r1) return;  // row outside this shard's band of tile rows (uniform)
     const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
     const int px = tx * TILE + lx, py = ty * TILE + ly;
     const bool inside = px < p.W && py < p.H;
@@ -614,20 +617,22 @@ __attribute__((amdgpu_waves_per_eu(DMR_HITS_WAVES, DMR_HITS_WAVES)))
 #endif
 __global__ void __launch_bounds__(256)
 k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits,
-                    const unsigned long long* __restrict__ hit_total, uint32_t capacity,
+                    const uint32_t* __restrict__ range_begin, const uint32_t* __restrict__ range_end, uint32_t capacity,
                     float* __restrict__ vrow, float* __restrict__ frow) {
-    const uint32_t nhits = (uint32_t)min((unsigned long long)capacity, *hit_total);
+    // records [*range_begin, *range_end) of the tiles of one band (exclusive scan of the per-tile hit counts),
+    // clamped to the buffer capacity while a size guess is being refuted
+    const uint32_t first = min(capacity, *range_begin), nhits = min(capacity, *range_end);
     __shared__ HitsLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t HW = (int64_t)p.H * p.W;
     // every wave owns a contiguous range of hit records, so that the dedup window of flush_staged sees
     // neighbouring list entries
-    const uint32_t nwaves = gridDim.x * 4u, niter = (nhits + 63u) / 64u;
+    const uint32_t nwaves = gridDim.x * 4u, niter = (nhits - first + 63u) / 64u;
     const uint32_t per_wave = (niter + nwaves - 1u) / nwaves;
     const uint32_t it0 = min(niter, (blockIdx.x * 4u + (uint32_t)wave) * per_wave), it1 = min(niter, it0 + per_wave);
     int staged = 0;
     for (uint32_t it = it0; it < it1; it++) {
-        const uint32_t base = it * 64u;
+        const uint32_t base = first + it * 64u;
         const uint32_t hi_idx = base + lane;
         const bool valid = hi_idx < nhits;
         int k = -1 - lane;  // invalid lanes: unique keys
@@ -808,26 +813,27 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
     k_tri_forward<FWD_CHUNK><<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, out_color, out_depth);
 }
 
-void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
+void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, int q0, int q1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
                              uint32_t capacity, hipStream_t st) {
-    if (r1 <= r0) return;
+    if (r1 <= r0 || q1 <= q0) return;
     TriParams p = make_params(s, gx, gy, r0, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
-    k_tri_backward_pix<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity);
+    k_tri_backward_pix<<<dim3(gx, q1 - q0, 1), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity, q0, r1);
 }
 
 void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
-                              uint32_t capacity, float* vrow, float* frow, hipStream_t st) {
-    if (capacity == 0) return;
-    const uint32_t nhits = capacity;  // grid size from the host-known bound
+                              const float4* pixrec, const HitRecord* hits, const uint32_t* range_begin,
+                              const uint32_t* range_end, uint32_t capacity, uint32_t expected, float* vrow, float* frow,
+                              hipStream_t st) {
+    if (capacity == 0 || expected == 0) return;
     TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr};
     TriParams p = make_params(s, 0, 0, 0, vproj, nullptr, face_list, none);
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((nhits + 255u) / 256u, 256u * 16u);
+    // grid from the host-side estimate of the band's record count; the kernel reads the exact range on the device
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)expected + 2047u) / 2048u, 256u * 16u);  // >= 8 rounds of 64 records per wave
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
-    k_tri_backward_hits<<<dim3(blocks), dim3(256), 0, st>>>(p, pixrec, hits, hit_total, capacity, vrow, frow);
+    k_tri_backward_hits<<<dim3(std::max(1u, blocks)), dim3(256), 0, st>>>(p, pixrec, hits, range_begin, range_end, capacity, vrow, frow);
 }
 
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,

@@ -14,7 +14,7 @@
  * Plain pointers and sizes only: every pointer is a DEVICE pointer unless stated,
  * tensors are dense row-major fp32 / int32 exactly as render.cu hands them down
  * (`.contiguous().data<T>()`), matrices are [B,16] column-major m[4*col+row]
- * (auxiliary.h:71-90).  `stream` is a hipStream_t (NULL = default stream).  All work
+ * (auxiliary.h:71-90) unless dmr_scene.mats_transposed says otherwise.  `stream` is a hipStream_t (NULL = default stream).  All work
  * is enqueued on that stream; the only host synchronisation is the 4-byte read of
  * num_rendered in the forward calls (reference: rasterizer_impl.cu:287-292).
  *
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DMR_ABI_VERSION 1
+#define DMR_ABI_VERSION 2
 
 /* Scratch buffers.  The first four are the reference's pointBuffer / faceBuffer /
  * binningBuffer / imageBuffer (rasterizer.h:14-17): opaque byte buffers that the
@@ -67,6 +67,13 @@ typedef struct dmr_scene {
     /* Tile-row band [row_begin, row_end) this call renders (multi-GPU shard by tile
      * rows); 0,0 means all rows.  Pixels outside the band are left untouched. */
     int32_t row_begin, row_end;
+    /* Bit i set (0 mv, 1 proj, 2 inv_mv, 3 inv_proj): matrix i is handed over with its 4x4 blocks transposed,
+     * i.e. element k of the [B,16] contract above lives at 16*b + 4*(k & 3) + (k >> 2).  That is the storage
+     * behind the `.transpose(1, 2)` views the reference wrapper passes (dmesh_renderer/__init__.py:219-220)
+     * and behind th.inverse of such a view, so the glue need not launch the four `.contiguous()` copies of
+     * render.cu:117-120.  The forward stores the matrices in contract layout in the image buffer; the
+     * backward reads them from there (its matrix arguments are not dereferenced). */
+    int32_t mats_transposed;
 } dmr_scene;
 
 /* out_color [B,3,H,W], out_depth [B,1,H,W]: every pixel of the rendered tile rows is written; the caller
