@@ -50,7 +50,7 @@ struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* ti
 struct ImageState {
     uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_cursor; int* num_rendered;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits; uint32_t* hit_offset; unsigned long long* hit_total;
+    uint32_t* tile_hits; uint32_t* hit_offset; unsigned long long* hit_total; uint32_t* tile_order;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
 };
@@ -72,6 +72,7 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
     s.final_T = c.take<float>(npix); s.final_prev_T = c.take<float>(npix); s.n_contrib = c.take<uint32_t>(npix);
     s.tile_hits = c.take<uint32_t>(ntiles); s.hit_offset = c.take<uint32_t>(ntiles + 1);
     s.hit_total = c.take<unsigned long long>(1);
+    s.tile_order = c.take<uint32_t>(ntiles);
     if (tet) {
         s.first_face = c.take<int32_t>(npix); s.first_tet = c.take<int32_t>(npix);
         s.last_face = c.take<int32_t>(npix); s.last_tet = c.take<int32_t>(npix);
@@ -172,7 +173,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         dmr::launch_project_verts(*s, ps.vproj, is.mats, st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
-        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, st);
+        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, is.tile_order, st);
         return 0;
     };
     auto rest = [&](uint64_t capacity) -> int {
@@ -183,7 +184,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (capacity > 0) {
             dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
                                       (uint32_t)capacity, st);
-            dmr::launch_sort_tiles(d.ntiles, is.tile_offset, bs.keys, bs.face_list, st);
+            dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, st);
         }
         if (!tet) DMR_HIP(hipMemsetAsync(is.tile_hits, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
         render(bs);
@@ -300,7 +301,7 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_order};
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
                                 out_depth, st);
@@ -351,14 +352,14 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
         dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
         DMR_HIP(hipMemsetAsync(work, 0, vbytes + fbytes, st));
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_order};
         const dmr_scene sc = canonical(s, is.mats);
         // One band = the whole flattened (view, tile row) range.  Splitting it into bands whose hit-parallel kernel
         // runs on a second stream while the next band's per-pixel kernel computes (atomic unit and SIMDs busy at
         // the same time) was measured and lost: 0.56 ms per step with 1 band, 0.64 with 2, 0.70 with 4 (C4) --
         // cross-stream event waits cost more than the overlap gains.
         const int nq = s->B * d.gy;
-        dmr::launch_tri_backward_pix(sc, d.gx, d.gy, d.r0, d.r1, 0, nq, ps.vproj, is.tile_offset, bs.face_list, img,
+        dmr::launch_tri_backward_pix(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img,
                                      dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity, st);
         dmr::launch_tri_backward_hits(sc, ps.vproj, bs.face_list, pixrec, hits, is.hit_offset,
                                       is.hit_offset + (size_t)nq * d.gx, (uint32_t)capacity, (uint32_t)capacity, vrow, frow, st);

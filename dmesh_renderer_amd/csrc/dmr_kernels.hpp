@@ -30,17 +30,19 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
                         uint2* face_rect, float* key_depth, float* max_depth, uint32_t* tiles_touched,
                         uint32_t* tile_count, hipStream_t st);
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
-                       int* num_rendered, hipStream_t st);
+                       int* num_rendered, uint32_t* tile_order, hipStream_t st);
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
                           const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
                           hipStream_t st);
-void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, hipStream_t st);
+void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
+                       uint32_t* face_list, hipStream_t st);
 
 // ---- tri compositing (dmr_tri.hip)
 struct TriImageState {
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
     uint32_t* tile_hits;    // blended (pixel, face) pairs per tile, counted by the forward
     uint32_t* hit_offset;   // exclusive scan of tile_hits (backward)
+    const uint32_t* tile_order;  // all B * gx * gy tiles, longest list first (k_scan_tiles)
 };
 // One blended (pixel, face) pair, written face-major per (tile, chunk, pass) by k_tri_backward_pix and
 // consumed one per lane by k_tri_backward_hits.
@@ -51,8 +53,7 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
                         float* out_color, float* out_depth, hipStream_t st);
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
                       hipStream_t st);
-// [q0, q1): band of the flattened (view, tile row) index; rows outside [r0, r1) of a view are skipped
-void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, int q0, int q1, const float4* vproj,
+void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
                              uint32_t capacity, hipStream_t st);

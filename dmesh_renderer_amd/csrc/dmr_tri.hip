@@ -60,17 +60,34 @@ struct alignas(16) ShadeRec {
 static_assert(sizeof(ShadeRec) == 112, "ShadeRec");
 
 struct TriParams {
-    int B, P, F, W, H, gx, gy, r0, dbg;
+    int B, P, F, W, H, gx, gy, r0, r1, dbg;
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* inv_mv; const float* inv_proj; const float* faces_intense; const float* bg;
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits; const uint32_t* hit_offset;
+    uint32_t* tile_hits; const uint32_t* hit_offset; const uint32_t* tile_order;
 };
 
-__device__ __forceinline__ void stage_face(const TriParams& p, int b, int face, int x0, int y0, V3 ray_o,
-                                          CovRec& cov, ShadeRec& sh, int* vid) {
-    const int v0 = p.faces[3 * face], v1 = p.faces[3 * face + 1], v2 = p.faces[3 * face + 2];
+// Staging a list entry is a chain of dependent gathers: face_list -> faces (+ opacity, intensity) -> 3 x
+// (projected vertex, position, colour).  While the workgroup waits for it nothing else runs, so the first two
+// levels are software-pipelined: the ids of chunk c + 1 are loaded while chunk c is being composited (6 VGPRs),
+// and staging a chunk only exposes the last level.
+struct FaceIds { int face, v0, v1, v2; float opacity, intense; };
+
+__device__ __forceinline__ FaceIds load_face_ids(const TriParams& p, int b, int face) {
+    FaceIds f;
+    f.face = face;
+    if (face >= 0) {
+        f.v0 = p.faces[3 * face]; f.v1 = p.faces[3 * face + 1]; f.v2 = p.faces[3 * face + 2];
+        f.opacity = p.faces_opacity[face];
+        f.intense = p.faces_intense[(int64_t)b * p.F + face];
+    } else { f.v0 = f.v1 = f.v2 = 0; f.opacity = 0.f; f.intense = 0.f; }
+    return f;
+}
+
+__device__ __forceinline__ void stage_face(const TriParams& p, int b, const FaceIds& f, int x0, int y0, V3 ray_o,
+                                          CovRec& cov, ShadeRec& sh) {
+    const int v0 = f.v0, v1 = f.v1, v2 = f.v2;
     const float4 a0 = p.vproj[(int64_t)b * p.P + v0];
     const float4 a1 = p.vproj[(int64_t)b * p.P + v1];
     const float4 a2 = p.vproj[(int64_t)b * p.P + v2];
@@ -92,9 +109,8 @@ __device__ __forceinline__ void stage_face(const TriParams& p, int b, int face, 
     sh.c1[0] = c1.x; sh.c1[1] = c1.y; sh.c1[2] = c1.z;
     sh.c2[0] = c2.x; sh.c2[1] = c2.y; sh.c2[2] = c2.z;
     sh.d0 = a0.w; sh.d1 = a1.w; sh.d2 = a2.w;
-    sh.opacity = p.faces_opacity[face];
-    sh.intense = p.faces_intense[(int64_t)b * p.F + face];
-    if (vid) { vid[0] = v0; vid[1] = v1; vid[2] = v2; vid[3] = face; }
+    sh.opacity = f.opacity;
+    sh.intense = f.intense;
 }
 
 __device__ __forceinline__ void stage_null(CovRec& cov) {
@@ -133,8 +149,14 @@ __device__ __forceinline__ void rasterize_faces(const CovRec* __restrict__ cov, 
     }
 }
 
+#ifndef DMR_FWD_WAVES
+#define DMR_FWD_WAVES 4
+#endif
+#ifndef DMR_PIX_WAVES
+#define DMR_PIX_WAVES 5
+#endif
 template <int CHUNK>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, DMR_FWD_WAVES)
 k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ out_depth) {
     constexpr int WORDS = CHUNK / 32;
     static_assert(WORDS == 4, "one 32-face block per wave");
@@ -143,7 +165,10 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     __shared__ uint32_t s_pm[TILE_PIX][WORDS];  // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
+    // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
+    const int tile = (int)p.tile_order[blockIdx.x];
+    const int tx = tile % p.gx, ty = (tile / p.gx) % p.gy, b = tile / (p.gx * p.gy);
+    if (ty < p.r0 || ty >= p.r1) return;  // uniform
     const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
     const int px = tx * TILE + lx, py = ty * TILE + ly;
     const bool inside = px < p.W && py < p.H;
@@ -154,19 +179,23 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     if (inside) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
     const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
 
-    const int tile = (b * p.gy + ty) * p.gx + tx;
     const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
 
     float T = 1.0f, pT = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
-    uint32_t last_contributor = 0, n_hits = 0;
+    uint32_t last_contributor = 0, n_hits = 0, n_skipped = 0;
     bool done = !inside;
+
+    // staging pipeline (threads < CHUNK): ids of the current chunk, face id of the next one
+    FaceIds ids = load_face_ids(p, b, (tid < CHUNK && begin + tid < end) ? (int)p.face_list[begin + tid] : -1);
+    int face_next = (tid < CHUNK && begin + CHUNK + tid < end) ? (int)p.face_list[begin + CHUNK + tid] : -1;
 
     for (uint32_t base = begin; base < end; base += CHUNK) {
         if (__syncthreads_and(done)) break;  // also fences LDS reuse
         const int n = (int)min((uint32_t)CHUNK, end - base);
-        if (tid < n && !(p.dbg & 32)) stage_face(p, b, (int)p.face_list[base + tid], tx * TILE, ty * TILE, view_o,
-                                                 s_cov[tid], s_shade[tid], nullptr);
+        if (tid < n) stage_face(p, b, ids, tx * TILE, ty * TILE, view_o, s_cov[tid], s_shade[tid]);
         else if (tid < CHUNK) stage_null(s_cov[tid]);
+        ids = load_face_ids(p, b, face_next);  // in flight while this chunk is composited
+        face_next = (tid < CHUNK && base + 2 * CHUNK + tid < end) ? (int)p.face_list[base + 2 * CHUNK + tid] : -1;
         *reinterpret_cast<uint4*>(&s_pm[tid][0]) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         if (!(p.dbg & 16)) rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // A
@@ -195,7 +224,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
             const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
             const V3 Pv = cross(rd, E2);
             const float denom = dot(Pv, E1);
-            if (denom == 0.0f) continue;  // "edge case": counted, not blended (forward.cu:429-430)
+            if (denom == 0.0f) { n_skipped++; continue; }  // "edge case": counted, not blended (forward.cu:429-430)
             const float inv_denom = 1.0f / denom;
             const float iu = dot(Pv, Tv) * inv_denom;
             const float iv = dot(Q, rd) * inv_denom;
@@ -213,7 +242,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
             D += iD * alpha * T;
             pT = T; T = test_T;
             last_contributor = (base - begin) + (uint32_t)k + 1u;
-            n_hits++;
+            n_hits += 1u + n_skipped; n_skipped = 0u;  // the backward lists every covered pair below n_contrib, skipped ones too
             if (T < T_EPS) { done = true; break; }  // blend first, test after (Q9)
         }
     }
@@ -295,43 +324,75 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
 // backward, kernel 1 of 2: k_tri_backward_pix -- the per-pixel sequential part.
 //
 // Per chunk of 64 list entries (walked from the back of the tile list):
-//   A. coverage as in the forward; every pixel gets a 64-bit mask `rem` of the chunk faces covering it
-//      (positions >= its n_contrib masked off, backward.cu:192-194).
-//   B. in list order from the back: recover T (Q10), the running accum_rec terms and dL/dalpha
-//      (backward.cu:244-308).  At most BWD_SLOTS hits per pixel per pass; (T, dL_dalpha) of hit #h is
-//      parked in s_pool[h][pixel].
-//   C. the pass's hits are listed FACE-major (ballot transposes + block scan + scatter) and written out
-//      as 16-byte HitRecords at the tile's offset (scan of the forward's per-tile hit counts).
+//   A. coverage as in the forward, restricted per pixel to list positions below its n_contrib
+//      (backward.cu:192-194): every pixel gets a 64-bit mask of the chunk faces it blended, and every face the
+//      number of such pixels (counted by the rasterising threads, one ds_add_u32 per thread).
+//   S. one wave scans the 64 counts: face-major slot ranges inside the tile's record region (the region itself
+//      starts at the scan of the per-tile hit counts the forward accumulated).
+//   B. every pixel walks its mask from the back: recover T (Q10), the running accum_rec terms and dL/dalpha
+//      (backward.cu:244-308), claim a slot of the face with a returning ds_add_u32 and write the 16-byte
+//      HitRecord straight to HBM.  Within a face the records are in claim order, which kernel 2 does not care about.
 // Everything that needs 23 accumulators per face happens in kernel 2, so this kernel keeps the forward's
-// register/LDS footprint.  History of the fused versions (all measured at C4, see profiles/r01):
-// 23 ds_add_f32 per hit: 59 % of wave cycles stalled on LDS issue (1.26 ms); one thread per
-// (face, quadrant) accumulating in registers: ~15 % lane utilisation (1.25 ms); hit-parallel phase with a
-// segmented scan inside this kernel: 168 VGPRs + 50 KB LDS -> 3 waves/SIMD, 0.56 ms.
+// register/LDS footprint.  History (all measured at C4, see profiles/r01): fused versions -- 23 ds_add_f32 per
+// hit: 59 % of wave cycles stalled on LDS issue (1.26 ms); one thread per (face, quadrant) accumulating in
+// registers: ~15 % lane utilisation (1.25 ms); hit-parallel phase with a segmented scan inside this kernel: 168
+// VGPRs + 50 KB LDS -> 3 waves/SIMD, 0.56 ms.  Two-kernel versions -- hits parked in an LDS pool per pass of at
+// most 8 per pixel, transposed face-major by 64 wave ballots + block scan (0.274 ms), by per-pass counting with
+// integer LDS atomics (0.146 ms); counting during rasterisation removed the passes, the pool and 4 of the ~9
+// barriers per chunk.
 // ---------------------------------------------------------------------------
-#ifndef DMR_BWD_SLOTS
-#define DMR_BWD_SLOTS 8
-#endif
-constexpr int BWD_SLOTS = DMR_BWD_SLOTS;
+constexpr uint32_t HIT_SKIPPED = 0xffffffffu;  // HitRecord.pixel of a covered pair the forward skipped (denom == 0)
 
-__global__ void __launch_bounds__(256)
+// rasterize_faces of the forward plus: only list positions below the pixel's n_contrib (s_lim = that bound relative
+// to the chunk start) get their bit, and the face's blended-pixel count goes to s_fcnt.
+template <int CHUNK>
+__device__ __forceinline__ void rasterize_faces_counted(const CovRec* __restrict__ cov, int n, int tid,
+                                                        uint32_t (*__restrict__ pm)[CHUNK / 32],
+                                                        const uint32_t* __restrict__ s_lim, uint32_t* __restrict__ s_fcnt) {
+    constexpr int TPF = 256 / CHUNK;  // threads per face
+    const int j = tid / TPF, sub = tid % TPF;
+    if (j >= n) return;
+    const CovRec& c = cov[j];
+    const int fl = c.flags;
+    if (!(fl & COV_VALID)) return;
+    const int x0 = fl & 15, x1 = (fl >> 4) & 15, y0 = (fl >> 8) & 15, y1 = (fl >> 12) & 15;
+    const uint32_t bit = 1u << (j & 31);
+    const int word = j >> 5;
+    const uint32_t bx0 = (uint32_t)c.bx[0], bx1 = (uint32_t)c.bx[1], bx2 = (uint32_t)c.bx[2];
+    uint32_t cnt = 0;
+    for (int y = y0 + sub; y <= y1; y += TPF) {
+        uint32_t e0 = (uint32_t)c.s0[0] + (uint32_t)c.by[0] * (uint32_t)y + bx0 * (uint32_t)x0;
+        uint32_t e1 = (uint32_t)c.s0[1] + (uint32_t)c.by[1] * (uint32_t)y + bx1 * (uint32_t)x0;
+        uint32_t e2 = (uint32_t)c.s0[2] + (uint32_t)c.by[2] * (uint32_t)y + bx2 * (uint32_t)x0;
+        for (int x = x0; x <= x1; x++) {
+            if ((int32_t)(e0 & e1 & e2) < 0 && s_lim[y * TILE + x] > (uint32_t)j) {
+                atomicOr(&pm[y * TILE + x][word], bit);
+                cnt++;
+            }
+            e0 += bx0; e1 += bx1; e2 += bx2;
+        }
+    }
+    if (cnt) atomicAdd(&s_fcnt[j], cnt);
+}
+
+__global__ void __launch_bounds__(256, DMR_PIX_WAVES)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity, int q0, int r1) {
+                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity) {
     constexpr int CHUNK = 64;
     static_assert(BWD_CHUNK == CHUNK, "64-bit per-pixel masks, one wave scans the 64 face counters");
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
-    __shared__ uint32_t s_fcnt[CHUNK];              // hits per face this pass
-    __shared__ uint32_t s_fcur[CHUNK];              // claim cursor per face
-    __shared__ uint32_t s_fstart[CHUNK + 1];        // exclusive scan of s_fcnt
-    __shared__ float2 s_pool[BWD_SLOTS][TILE_PIX];  // [hit ordinal from the back][pixel] = (T, dL_dalpha)
+    __shared__ uint32_t s_fcnt[CHUNK];              // blended pixels per face of the chunk
+    __shared__ uint32_t s_fcur[CHUNK];              // exclusive scan of s_fcnt, then the claim cursor per face
+    __shared__ uint32_t s_lim[TILE_PIX];            // per pixel: n_contrib relative to the chunk start, clamped to [0, 64]
     __shared__ uint32_t s_pm[TILE_PIX][CHUNK / 32]; // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
-    __shared__ uint32_t s_max_last;
+    __shared__ uint32_t s_max_last, s_chunk_hits;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // blockIdx.y walks the flattened (view, tile row) index from q0: a band of the backward (see dmr_api.hip)
-    const int q = q0 + (int)blockIdx.y;
-    const int tx = blockIdx.x, ty = q % p.gy, b = q / p.gy;
-    if (ty < p.r0 || ty >= r1) return;  // row outside this shard's band of tile rows (uniform)
+    // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
+    const int tile = (int)p.tile_order[blockIdx.x];
+    const int tx = tile % p.gx, ty = (tile / p.gx) % p.gy, b = tile / (p.gx * p.gy);
+    if (ty < p.r0 || ty >= p.r1) return;  // uniform
     const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
     const int px = tx * TILE + lx, py = ty * TILE + ly;
     const bool inside = px < p.W && py < p.H;
@@ -339,7 +400,6 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     const int64_t pix_id = (int64_t)p.W * py + px;
     const int64_t bpix = (int64_t)b * HW + pix_id;
 
-    const int tile = (b * p.gy + ty) * p.gx + tx;
     const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
     if (begin == end) return;  // uniform
     uint32_t hit_cursor = p.hit_offset[tile];
@@ -368,7 +428,6 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     const float bd_dot = 0.f + (float)(1.0 * (double)dpd);
 
     if (tid == 0) s_max_last = 0;
-    if (tid < CHUNK) s_fcnt[tid] = 0u;
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_last, last_contributor);
     __syncthreads();
@@ -380,121 +439,102 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     bool first_pass = true;
     float acr0 = 0, acr1 = 0, acr2 = 0, acrd = 0;
     float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0;
-
+    const uint32_t pixel = (uint32_t)bpix;
+    const int pl = ly * TILE + lx;  // tile-local pixel index
 
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
+    // staging pipeline (threads < CHUNK), chunks walked from the back: chunk ci = list positions [lo, hi) with
+    // hi = total - ci * CHUNK; thread t stages position lo + t
+    auto chunk_face = [&](uint32_t ci) -> int {
+        if (tid >= CHUNK || ci >= nchunks) return -1;
+        const uint32_t hi = total - ci * CHUNK, lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
+        return lo + (uint32_t)tid < hi ? (int)p.face_list[begin + lo + tid] : -1;
+    };
+    FaceIds ids = load_face_ids(p, b, chunk_face(0));
+    int face_next = chunk_face(1);
     for (uint32_t ci = 0; ci < nchunks; ci++) {
         const uint32_t hi = total - ci * CHUNK;  // chunk = list positions [lo, hi)
         const uint32_t lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
         const int n = (int)(hi - lo);
-        __syncthreads();  // previous chunk is done with the LDS records
-        if (tid < n)
-            stage_face(p, b, (int)p.face_list[begin + lo + tid], tx * TILE, ty * TILE, view_o,
-                       s_cov[tid], s_shade[tid], nullptr);
+        __syncthreads();  // previous chunk is done with the LDS records, counters and masks
+        if (tid < n) stage_face(p, b, ids, tx * TILE, ty * TILE, view_o, s_cov[tid], s_shade[tid]);
         else if (tid < CHUNK) stage_null(s_cov[tid]);
-        *reinterpret_cast<uint2*>(&s_pm[tid][0]) = make_uint2(0u, 0u);
+        ids = load_face_ids(p, b, face_next);  // in flight while this chunk is processed
+        face_next = chunk_face(ci + 2);
+        if (tid < CHUNK) s_fcnt[tid] = 0u;
+        *reinterpret_cast<uint2*>(&s_pm[pl][0]) = make_uint2(0u, 0u);
+        s_lim[pl] = last_contributor > lo ? min(last_contributor - lo, (uint32_t)CHUNK) : 0u;
         __syncthreads();
-        rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // ---- A
+        if (!(p.dbg & 4)) rasterize_faces_counted<CHUNK>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // ---- A
         __syncthreads();
+        if (wave == 0) {  // ---- S
+            const int c = (int)s_fcnt[lane];
+            int incl = c;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int o = __shfl_up(incl, dlt, 64);
+                if (lane >= dlt) incl += o;
+            }
+            s_fcur[lane] = (uint32_t)(incl - c);
+            if (lane == 63) s_chunk_hits = (uint32_t)incl;
+        }
+        __syncthreads();
+        // ---- B
         uint64_t rem;
         {
-            const uint2 mm = *reinterpret_cast<const uint2*>(&s_pm[ly * TILE + lx][0]);
+            const uint2 mm = *reinterpret_cast<const uint2*>(&s_pm[pl][0]);
             rem = (uint64_t)mm.x | ((uint64_t)mm.y << 32);
-            const int64_t lim = (int64_t)last_contributor - (int64_t)lo;  // keep positions < last_contributor
-            if (lim <= 0) rem = 0;
-            else if (lim < 64) rem &= (1ull << lim) - 1ull;
         }
-
-        while (__syncthreads_or(rem != 0ull)) {
-            // ---- B: up to BWD_SLOTS hits of this pixel, from the back
-            uint64_t pm = 0;
-            int h = 0;
-            if (p.dbg & 4) rem = 0ull;
-            while (rem != 0ull && h < BWD_SLOTS) {
-                const int k = 63 - __clzll((long long)rem);
-                const uint64_t bit = 1ull << k;
-                rem &= ~bit;
-                const ShadeRec& r = s_shade[k];
-                const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
-                const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
-                const V3 Pv = cross(rd, E2);
-                const float denom = dot(Pv, E1);
-                if (denom == 0.0f) continue;  // "edge case": skipped entirely (backward.cu:215-216)
-                const float inv_denom = fast_rcp(denom);
-                const float iu = dot(Pv, Tv) * inv_denom;
-                const float iv = dot(Q, rd) * inv_denom;
-                float iuc, ivc; int code;
-                clamp_bary_uv(iu, iv, iuc, ivc, code);
-                const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
-                const float intense = r.intense;
-                const float iC0 = (i0 * r.c0[0] + i1 * r.c1[0] + i2 * r.c2[0]) * intense;
-                const float iC1 = (i0 * r.c0[1] + i1 * r.c1[1] + i2 * r.c2[1]) * intense;
-                const float iC2 = (i0 * r.c0[2] + i1 * r.c1[2] + i2 * r.c2[2]) * intense;
-                const float iD = i0 * r.d0 + i1 * r.d1 + i2 * r.d2;
-                const float alpha = r.opacity;
-                const float inv_1ma = fast_rcp(1.f - alpha);
-                if (!first_pass) T = T * inv_1ma;  // Q10
-                first_pass = false;
-                float dL_dalpha = 0.0f;
-                acr0 = last_alpha * lc0 + (1.f - last_alpha) * acr0; lc0 = iC0; dL_dalpha += (iC0 - acr0) * dpc0;
-                acr1 = last_alpha * lc1 + (1.f - last_alpha) * acr1; lc1 = iC1; dL_dalpha += (iC1 - acr1) * dpc1;
-                acr2 = last_alpha * lc2 + (1.f - last_alpha) * acr2; lc2 = iC2; dL_dalpha += (iC2 - acr2) * dpc2;
-                acrd = last_alpha * last_depth + (1.f - last_alpha) * acrd; last_depth = iD;
-                dL_dalpha += (iD - acrd) * dpd;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                if (alpha == 1.0f) {
-                    dL_dalpha += (-prev_T_final) * bg_dot;
-                    dL_dalpha += (-prev_T_final) * bd_dot;
-                } else {
-                    dL_dalpha += (-T_final * inv_1ma) * bg_dot;
-                    dL_dalpha += (-T_final * inv_1ma) * bd_dot;
-                }
-                s_pool[h][tid] = make_float2(T, dL_dalpha);
-                atomicAdd(&s_fcnt[k], 1u);
-                pm |= bit;
-                h++;
+        while (rem != 0ull) {
+            const int k = 63 - __clzll((long long)rem);
+            rem &= ~(1ull << k);
+            const uint32_t slot = hit_cursor + atomicAdd(&s_fcur[k], 1u);
+            HitRecord hr;
+            hr.entry = begin + lo + (uint32_t)k;
+            const ShadeRec& r = s_shade[k];
+            const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
+            const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
+            const V3 Pv = cross(rd, E2);
+            const float denom = dot(Pv, E1);
+            if (denom == 0.0f) {  // "edge case": skipped entirely (backward.cu:215-216); its slot says so
+                hr.pixel = HIT_SKIPPED; hr.T = 0.f; hr.dL_dalpha = 0.f;
+                if (slot < capacity) hits[slot] = hr;
+                continue;
             }
-            // ---- C: face-major slots.  Integer LDS atomics run at full rate on gfx950 (4 cycles per wave
-            // instruction when conflict-free; ds_add_f32 takes ~200), so the (pixel, face) -> face-major
-            // transposition is: count per face (B did that), scan the 64 counts, then every pixel claims a
-            // slot per hit with a returning ds_add and writes its 16-byte record straight to the tile's region.
-            __syncthreads();  // all counts of this pass are in
-            if (wave == 0) {
-                const int c = (lane < n) ? (int)s_fcnt[lane] : 0;
-                int incl = c;
-#pragma unroll
-                for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                    const int o = __shfl_up(incl, dlt, 64);
-                    if (lane >= dlt) incl += o;
-                }
-                s_fstart[lane] = (uint32_t)(incl - c);
-                if (lane == 63) s_fstart[64] = (uint32_t)incl;
-                s_fcnt[lane] = 0u;  // clean for the next pass
-                s_fcur[lane] = 0u;
+            const float inv_denom = fast_rcp(denom);
+            const float iu = dot(Pv, Tv) * inv_denom;
+            const float iv = dot(Q, rd) * inv_denom;
+            float iuc, ivc; int code;
+            clamp_bary_uv(iu, iv, iuc, ivc, code);
+            const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
+            const float intense = r.intense;
+            const float iC0 = (i0 * r.c0[0] + i1 * r.c1[0] + i2 * r.c2[0]) * intense;
+            const float iC1 = (i0 * r.c0[1] + i1 * r.c1[1] + i2 * r.c2[1]) * intense;
+            const float iC2 = (i0 * r.c0[2] + i1 * r.c1[2] + i2 * r.c2[2]) * intense;
+            const float iD = i0 * r.d0 + i1 * r.d1 + i2 * r.d2;
+            const float alpha = r.opacity;
+            const float inv_1ma = fast_rcp(1.f - alpha);
+            if (!first_pass) T = T * inv_1ma;  // Q10
+            first_pass = false;
+            float dL_dalpha = 0.0f;
+            acr0 = last_alpha * lc0 + (1.f - last_alpha) * acr0; lc0 = iC0; dL_dalpha += (iC0 - acr0) * dpc0;
+            acr1 = last_alpha * lc1 + (1.f - last_alpha) * acr1; lc1 = iC1; dL_dalpha += (iC1 - acr1) * dpc1;
+            acr2 = last_alpha * lc2 + (1.f - last_alpha) * acr2; lc2 = iC2; dL_dalpha += (iC2 - acr2) * dpc2;
+            acrd = last_alpha * last_depth + (1.f - last_alpha) * acrd; last_depth = iD;
+            dL_dalpha += (iD - acrd) * dpd;
+            dL_dalpha *= T;
+            last_alpha = alpha;
+            if (alpha == 1.0f) {
+                dL_dalpha += (-prev_T_final) * bg_dot;
+                dL_dalpha += (-prev_T_final) * bd_dot;
+            } else {
+                dL_dalpha += (-T_final * inv_1ma) * bg_dot;
+                dL_dalpha += (-T_final * inv_1ma) * bd_dot;
             }
-            __syncthreads();
-            const uint32_t Hp = s_fstart[64];
-            {
-                uint64_t m = pm;
-                int hh = 0;
-                const uint32_t pixel = (uint32_t)bpix;
-                while (m != 0ull) {
-                    const int k = 63 - __clzll((long long)m);
-                    m &= ~(1ull << k);
-                    const uint32_t slot = s_fstart[k] + atomicAdd(&s_fcur[k], 1u);
-                    const float2 rec = s_pool[hh][tid];
-                    hh++;
-                    HitRecord hr;
-                    hr.entry = begin + lo + (uint32_t)k;
-                    hr.pixel = pixel;
-                    hr.T = rec.x; hr.dL_dalpha = rec.y;
-                    if (hit_cursor + slot < capacity) hits[hit_cursor + slot] = hr;  // capacity < total only while a size guess is being refuted
-                }
-            }
-            hit_cursor += Hp;
-            __syncthreads();  // claims done before wave 0 clears / rescans the counters in the next pass
+            hr.pixel = pixel; hr.T = T; hr.dL_dalpha = dL_dalpha;
+            if (slot < capacity) hits[slot] = hr;  // capacity < total only while a size guess is being refuted
         }
+        hit_cursor += s_chunk_hits;  // stable until the next chunk's scan, two barriers away
     }
 }
 
@@ -634,7 +674,9 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     for (uint32_t it = it0; it < it1; it++) {
         const uint32_t base = first + it * 64u;
         const uint32_t hi_idx = base + lane;
-        const bool valid = hi_idx < nhits;
+        HitRecord hr; hr.entry = 0u; hr.pixel = HIT_SKIPPED; hr.T = 0.f; hr.dL_dalpha = 0.f;
+        if (hi_idx < nhits) hr = hits[hi_idx];
+        const bool valid = hr.pixel != HIT_SKIPPED;  // past the end, or a covered pair the forward skipped (denom == 0)
         int k = -1 - lane;  // invalid lanes: unique keys
         int v0 = 0, v1 = 0, v2 = 0, face = 0, b = 0;
         float g[NACC];
@@ -642,7 +684,6 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         for (int c = 0; c < NACC; c++) g[c] = 0.f;
         if (valid) {
             using namespace fm;
-            const HitRecord hr = hits[hi_idx];
             k = (int)hr.entry;
             face = (int)p.face_list[hr.entry];
             b = (int)(hr.pixel / (uint32_t)HW);
@@ -791,16 +832,16 @@ k_tri_unpack(int B, int P, int F, const float* __restrict__ vrow, const float* _
     }
 }
 
-static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, const float4* vproj,
+static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img) {
     TriParams p;
-    p.B = s.B; p.P = s.P; p.F = s.F; p.W = s.W; p.H = s.H; p.gx = gx; p.gy = gy; p.r0 = r0;
+    p.B = s.B; p.P = s.P; p.F = s.F; p.W = s.W; p.H = s.H; p.gx = gx; p.gy = gy; p.r0 = r0; p.r1 = r1;
     { static const int dbg = getenv("DMR_ABLATE") ? atoi(getenv("DMR_ABLATE")) : 0; p.dbg = dbg; }  // timing ablations only
     p.verts = s.verts; p.faces = s.faces; p.verts_color = s.verts_color; p.faces_opacity = s.faces_opacity;
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
-    p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset;
+    p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset; p.tile_order = img.tile_order;
     return p;
 }
 
@@ -808,19 +849,19 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
                         const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                         float* out_color, float* out_depth, hipStream_t st) {
     if (r1 <= r0) return;
-    TriParams p = make_params(s, gx, gy, r0, vproj, tile_offset, face_list, img);
+    TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_FORWARD, st);
-    k_tri_forward<FWD_CHUNK><<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, out_color, out_depth);
+    k_tri_forward<FWD_CHUNK><<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, out_color, out_depth);
 }
 
-void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, int q0, int q1, const float4* vproj,
+void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
                              uint32_t capacity, hipStream_t st) {
-    if (r1 <= r0 || q1 <= q0) return;
-    TriParams p = make_params(s, gx, gy, r0, vproj, tile_offset, face_list, img);
+    if (r1 <= r0) return;
+    TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
-    k_tri_backward_pix<<<dim3(gx, q1 - q0, 1), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity, q0, r1);
+    k_tri_backward_pix<<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity);
 }
 
 void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
@@ -828,8 +869,8 @@ void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uin
                               const uint32_t* range_end, uint32_t capacity, uint32_t expected, float* vrow, float* frow,
                               hipStream_t st) {
     if (capacity == 0 || expected == 0) return;
-    TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr};
-    TriParams p = make_params(s, 0, 0, 0, vproj, nullptr, face_list, none);
+    TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    TriParams p = make_params(s, 0, 0, 0, 0, vproj, nullptr, face_list, none);
     // grid from the host-side estimate of the band's record count; the kernel reads the exact range on the device
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)expected + 2047u) / 2048u, 256u * 16u);  // >= 8 rounds of 64 records per wave
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
