@@ -33,7 +33,10 @@ namespace dmr {
 #define DMR_COV_UNROLL 1
 #endif
 constexpr int FWD_CHUNK = 128;
-constexpr int BWD_CHUNK = 64;
+#ifndef DMR_BWD_CHUNK
+#define DMR_BWD_CHUNK 128
+#endif
+constexpr int BWD_CHUNK = DMR_BWD_CHUNK;
 
 // s_i(x, y) = s0[i] + bx[i] * (x - x0) + by[i] * (y - y0) (mod 2^32), inside iff all three < 0.
 // A zero-area face (in_tri returns false, auxiliary.h:201-202) and the padding entries of a
@@ -85,20 +88,30 @@ __device__ __forceinline__ FaceIds load_face_ids(const TriParams& p, int b, int 
     return f;
 }
 
-__device__ __forceinline__ void stage_face(const TriParams& p, int b, const FaceIds& f, int x0, int y0, V3 ray_o,
-                                          CovRec& cov, ShadeRec& sh) {
-    const int v0 = f.v0, v1 = f.v1, v2 = f.v2;
-    const float4 a0 = p.vproj[(int64_t)b * p.P + v0];
-    const float4 a1 = p.vproj[(int64_t)b * p.P + v1];
-    const float4 a2 = p.vproj[(int64_t)b * p.P + v2];
-    const V3 p0 = load_v3(p.verts, v0), p1 = load_v3(p.verts, v1), p2 = load_v3(p.verts, v2);
-    const V3 c0 = load_v3(p.verts_color, v0), c1 = load_v3(p.verts_color, v1), c2 = load_v3(p.verts_color, v2);
+__device__ __forceinline__ void stage_null(CovRec& cov) {
+    int4* q = reinterpret_cast<int4*>(&cov);
+    q[0] = make_int4(0, 0, 0, 0); q[1] = make_int4(0, 0, 0, 0); q[2] = make_int4(0, 0, 0, 0);
+}
+
+// The two halves of staging a face: with 128-face chunks and 256 threads, waves 0-1 build the coverage records while
+// waves 2-3 build the shading records (one thread did both before, three waves waiting for the fourth).
+__device__ __forceinline__ void stage_cov(const TriParams& p, int b, const FaceIds& f, int x0, int y0, CovRec& cov) {
+    const float4 a0 = p.vproj[(int64_t)b * p.P + f.v0];
+    const float4 a1 = p.vproj[(int64_t)b * p.P + f.v1];
+    const float4 a2 = p.vproj[(int64_t)b * p.P + f.v2];
     EdgeSetup e = edge_setup({a0.x, a0.y}, {a1.x, a1.y}, {a2.x, a2.y}, x0, y0);
 #pragma unroll
     for (int i = 0; i < 3; i++) { cov.s0[i] = e.s0[i]; cov.bx[i] = e.bx[i]; cov.by[i] = e.by[i]; }
     const bool some = e.ok && e.x0 <= e.x1 && e.y0 <= e.y1;
     cov.flags = some ? (COV_VALID | e.x0 | (e.x1 << 4) | (e.y0 << 8) | (e.y1 << 12)) : 0;
     cov.pad0 = 0; cov.pad1 = 0;
+}
+
+__device__ __forceinline__ void stage_shade(const TriParams& p, int b, const FaceIds& f, V3 ray_o, ShadeRec& sh) {
+    const int v0 = f.v0, v1 = f.v1, v2 = f.v2;
+    const V3 p0 = load_v3(p.verts, v0), p1 = load_v3(p.verts, v1), p2 = load_v3(p.verts, v2);
+    const V3 c0 = load_v3(p.verts_color, v0), c1 = load_v3(p.verts_color, v1), c2 = load_v3(p.verts_color, v2);
+    const float d0 = p.vproj[(int64_t)b * p.P + v0].w, d1 = p.vproj[(int64_t)b * p.P + v1].w, d2 = p.vproj[(int64_t)b * p.P + v2].w;
     const V3 T = ray_o - p0, E1 = p1 - p0, E2 = p2 - p0;
     const V3 Q = cross(T, E1);
     sh.T[0] = T.x; sh.T[1] = T.y; sh.T[2] = T.z;
@@ -108,15 +121,25 @@ __device__ __forceinline__ void stage_face(const TriParams& p, int b, const Face
     sh.c0[0] = c0.x; sh.c0[1] = c0.y; sh.c0[2] = c0.z;
     sh.c1[0] = c1.x; sh.c1[1] = c1.y; sh.c1[2] = c1.z;
     sh.c2[0] = c2.x; sh.c2[1] = c2.y; sh.c2[2] = c2.z;
-    sh.d0 = a0.w; sh.d1 = a1.w; sh.d2 = a2.w;
+    sh.d0 = d0; sh.d1 = d1; sh.d2 = d2;
     sh.opacity = f.opacity;
     sh.intense = f.intense;
 }
 
-__device__ __forceinline__ void stage_null(CovRec& cov) {
-    int4* q = reinterpret_cast<int4*>(&cov);
-    q[0] = make_int4(0, 0, 0, 0); q[1] = make_int4(0, 0, 0, 0); q[2] = make_int4(0, 0, 0, 0);
+// thread tid stages face (tid mod CHUNK) of the chunk: its coverage record if tid < CHUNK, else its shading record
+template <int CHUNK>
+__device__ __forceinline__ void stage_chunk(const TriParams& p, int b, const FaceIds& ids, int n, int tid, int x0, int y0,
+                                            V3 ray_o, CovRec* __restrict__ s_cov, ShadeRec* __restrict__ s_shade) {
+    static_assert(CHUNK == 128, "256 threads = 128 coverage + 128 shading records");
+    const int j = tid & (CHUNK - 1);
+    if (tid < CHUNK) {
+        if (j < n) stage_cov(p, b, ids, x0, y0, s_cov[j]);
+        else stage_null(s_cov[j]);
+    } else if (j < n) {
+        stage_shade(p, b, ids, ray_o, s_shade[j]);
+    }
 }
+
 
 // Phase A, face-parallel.  256 / CHUNK threads rasterise one staged face each (interleaved rows of its pixel
 // box): the three fixed-point edge functions are stepped incrementally (+bx per pixel) and every covered
@@ -186,16 +209,16 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     bool done = !inside;
 
     // staging pipeline (threads < CHUNK): ids of the current chunk, face id of the next one
-    FaceIds ids = load_face_ids(p, b, (tid < CHUNK && begin + tid < end) ? (int)p.face_list[begin + tid] : -1);
-    int face_next = (tid < CHUNK && begin + CHUNK + tid < end) ? (int)p.face_list[begin + CHUNK + tid] : -1;
+    const int sj = tid & (CHUNK - 1);  // the chunk face this thread stages (see stage_chunk)
+    FaceIds ids = load_face_ids(p, b, begin + sj < end ? (int)p.face_list[begin + sj] : -1);
+    int face_next = begin + CHUNK + sj < end ? (int)p.face_list[begin + CHUNK + sj] : -1;
 
     for (uint32_t base = begin; base < end; base += CHUNK) {
         if (__syncthreads_and(done)) break;  // also fences LDS reuse
         const int n = (int)min((uint32_t)CHUNK, end - base);
-        if (tid < n) stage_face(p, b, ids, tx * TILE, ty * TILE, view_o, s_cov[tid], s_shade[tid]);
-        else if (tid < CHUNK) stage_null(s_cov[tid]);
+        stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
         ids = load_face_ids(p, b, face_next);  // in flight while this chunk is composited
-        face_next = (tid < CHUNK && base + 2 * CHUNK + tid < end) ? (int)p.face_list[base + 2 * CHUNK + tid] : -1;
+        face_next = base + 2 * CHUNK + sj < end ? (int)p.face_list[base + 2 * CHUNK + sj] : -1;
         *reinterpret_cast<uint4*>(&s_pm[tid][0]) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         if (!(p.dbg & 16)) rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // A
@@ -378,8 +401,9 @@ __device__ __forceinline__ void rasterize_faces_counted(const CovRec* __restrict
 __global__ void __launch_bounds__(256, DMR_PIX_WAVES)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity) {
-    constexpr int CHUNK = 64;
-    static_assert(BWD_CHUNK == CHUNK, "64-bit per-pixel masks, one wave scans the 64 face counters");
+    constexpr int CHUNK = BWD_CHUNK;
+    constexpr int WORDS = CHUNK / 32;
+    static_assert(CHUNK == 128, "one wave scans the face counters, two per lane; 256 threads stage 128 + 128 records");
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
     __shared__ uint32_t s_fcnt[CHUNK];              // blended pixels per face of the chunk
@@ -445,10 +469,11 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
     // staging pipeline (threads < CHUNK), chunks walked from the back: chunk ci = list positions [lo, hi) with
     // hi = total - ci * CHUNK; thread t stages position lo + t
+    const int sj = tid & (CHUNK - 1);  // the chunk face this thread stages (see stage_chunk)
     auto chunk_face = [&](uint32_t ci) -> int {
-        if (tid >= CHUNK || ci >= nchunks) return -1;
+        if (ci >= nchunks) return -1;
         const uint32_t hi = total - ci * CHUNK, lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
-        return lo + (uint32_t)tid < hi ? (int)p.face_list[begin + lo + tid] : -1;
+        return lo + (uint32_t)sj < hi ? (int)p.face_list[begin + lo + sj] : -1;
     };
     FaceIds ids = load_face_ids(p, b, chunk_face(0));
     int face_next = chunk_face(1);
@@ -457,37 +482,46 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         const uint32_t lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
         const int n = (int)(hi - lo);
         __syncthreads();  // previous chunk is done with the LDS records, counters and masks
-        if (tid < n) stage_face(p, b, ids, tx * TILE, ty * TILE, view_o, s_cov[tid], s_shade[tid]);
-        else if (tid < CHUNK) stage_null(s_cov[tid]);
+        stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
         ids = load_face_ids(p, b, face_next);  // in flight while this chunk is processed
         face_next = chunk_face(ci + 2);
         if (tid < CHUNK) s_fcnt[tid] = 0u;
-        *reinterpret_cast<uint2*>(&s_pm[pl][0]) = make_uint2(0u, 0u);
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) s_pm[pl][w] = 0u;
         s_lim[pl] = last_contributor > lo ? min(last_contributor - lo, (uint32_t)CHUNK) : 0u;
         __syncthreads();
         if (!(p.dbg & 4)) rasterize_faces_counted<CHUNK>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // ---- A
         __syncthreads();
-        if (wave == 0) {  // ---- S
-            const int c = (int)s_fcnt[lane];
-            int incl = c;
+        if (wave == 0) {  // ---- S: lane l scans counters [l * PER, (l + 1) * PER)
+            constexpr int PER = CHUNK / 64;
+            uint32_t c[PER]; uint32_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < PER; i++) { c[i] = s_fcnt[lane * PER + i]; sum += c[i]; }
+            uint32_t incl = sum;
 #pragma unroll
             for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                const int o = __shfl_up(incl, dlt, 64);
+                const uint32_t o = __shfl_up(incl, dlt, 64);
                 if (lane >= dlt) incl += o;
             }
-            s_fcur[lane] = (uint32_t)(incl - c);
-            if (lane == 63) s_chunk_hits = (uint32_t)incl;
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int i = 0; i < PER; i++) { s_fcur[lane * PER + i] = run; run += c[i]; }
+            if (lane == 63) s_chunk_hits = incl;
         }
         __syncthreads();
         // ---- B
-        uint64_t rem;
-        {
-            const uint2 mm = *reinterpret_cast<const uint2*>(&s_pm[pl][0]);
-            rem = (uint64_t)mm.x | ((uint64_t)mm.y << 32);
-        }
-        while (rem != 0ull) {
-            const int k = 63 - __clzll((long long)rem);
-            rem &= ~(1ull << k);
+        uint32_t m[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) m[w] = s_pm[pl][w];
+        while (true) {
+            int w = -1; uint32_t mw = 0;
+#pragma unroll
+            for (int q = 0; q < WORDS; q++) if (m[q]) { w = q; mw = m[q]; }  // highest non-empty word
+            if (w < 0) break;
+            const int bit = 31 - __clz((int)mw);
+#pragma unroll
+            for (int q = 0; q < WORDS; q++) if (q == w) m[q] = mw & ~(1u << bit);
+            const int k = 32 * w + bit;
             const uint32_t slot = hit_cursor + atomicAdd(&s_fcur[k], 1u);
             HitRecord hr;
             hr.entry = begin + lo + (uint32_t)k;
