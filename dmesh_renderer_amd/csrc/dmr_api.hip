@@ -67,12 +67,13 @@ size_t carve_face(void* b, size_t BF, bool tet, FaceState& s) {
 size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, ImageState& s) {
     Carver c(b);
     s.mats = c.take<float>(64 * B);
-    s.tile_count = c.take<uint32_t>(ntiles); s.tile_offset = c.take<uint32_t>(ntiles + 1);
+    // counters, zeroed by ONE memset at the start of a forward: [tile_count | tile_hits]
+    s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles);
+    s.hit_offset = c.take<uint32_t>(ntiles + 1); s.hit_total = c.take<unsigned long long>(1);
+    s.tile_offset = c.take<uint32_t>(ntiles + 1);
     s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(1);
-    s.final_T = c.take<float>(npix); s.final_prev_T = c.take<float>(npix); s.n_contrib = c.take<uint32_t>(npix);
-    s.tile_hits = c.take<uint32_t>(ntiles); s.hit_offset = c.take<uint32_t>(ntiles + 1);
-    s.hit_total = c.take<unsigned long long>(1);
     s.tile_order = c.take<uint32_t>(ntiles);
+    s.final_T = c.take<float>(npix); s.final_prev_T = c.take<float>(npix); s.n_contrib = c.take<uint32_t>(npix);
     if (tet) {
         s.first_face = c.take<int32_t>(npix); s.first_tet = c.take<int32_t>(npix);
         s.last_face = c.take<int32_t>(npix); s.last_tet = c.take<int32_t>(npix);
@@ -169,7 +170,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     int* host_R = reinterpret_cast<int*>(sr->slot);
 
     auto front = [&]() -> int {
-        DMR_HIP(hipMemsetAsync(is.tile_count, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
+        DMR_HIP(hipMemsetAsync(is.tile_count, 0, (size_t)(reinterpret_cast<char*>(is.tile_hits + d.ntiles) - reinterpret_cast<char*>(is.tile_count)), st));
         dmr::launch_project_verts(*s, ps.vproj, is.mats, st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
@@ -186,7 +187,6 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
                                       (uint32_t)capacity, st);
             dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, st);
         }
-        if (!tet) DMR_HIP(hipMemsetAsync(is.tile_hits, 0, sizeof(uint32_t) * (size_t)d.ntiles, st));
         render(bs);
         return 0;
     };
@@ -335,9 +335,8 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, false, is);
     carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, bs);
 
-    // The forward counted the blended (pixel, face) pairs per tile; their scan places every tile's hit
-    // records and the total sizes the record buffer (the backward's one 8-byte host read; speculative
-    // sizing as in the forward).
+    // The forward counted the blended (pixel, face) pairs per tile and in total; the total sizes the record
+    // buffer (the backward's one 8-byte host read; speculative sizing as in the forward).
     SizeRead* sr = size_read();
     if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
     unsigned long long* host_total = reinterpret_cast<unsigned long long*>(sr->slot);
@@ -351,18 +350,18 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         float* frow = reinterpret_cast<float*>(work + vbytes);
         float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
         dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
-        DMR_HIP(hipMemsetAsync(work, 0, vbytes + fbytes, st));
         dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_order};
         const dmr_scene sc = canonical(s, is.mats);
-        // One band = the whole flattened (view, tile row) range.  Splitting it into bands whose hit-parallel kernel
-        // runs on a second stream while the next band's per-pixel kernel computes (atomic unit and SIMDs busy at
-        // the same time) was measured and lost: 0.56 ms per step with 1 band, 0.64 with 2, 0.70 with 4 (C4) --
-        // cross-stream event waits cost more than the overlap gains.
-        const int nq = s->B * d.gy;
+        // (Splitting the tiles into bands whose hit-parallel kernel runs on a second stream while the next band's
+        // per-pixel kernel computes -- atomic unit and SIMDs busy at the same time -- was measured and lost: 0.56 ms
+        // per step with 1 band, 0.64 with 2, 0.70 with 4 at C4; cross-stream event waits cost more than the overlap.)
+        // k_tri_backward_pix also zeroes the packed accumulators (every block a slice).  (Handing out the tiles'
+        // record regions from an atomic cursor instead of k_scan_hits: the 2.9 k returning same-address atomics
+        // stall their waves, in order with every younger load -- 17 us against the scan's 6.)
         dmr::launch_tri_backward_pix(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img,
-                                     dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity, st);
-        dmr::launch_tri_backward_hits(sc, ps.vproj, bs.face_list, pixrec, hits, is.hit_offset,
-                                      is.hit_offset + (size_t)nq * d.gx, (uint32_t)capacity, (uint32_t)capacity, vrow, frow, st);
+                                     dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity,
+                                     reinterpret_cast<float*>(work), (vbytes + fbytes) / sizeof(float), st);
+        dmr::launch_tri_backward_hits(sc, ps.vproj, bs.face_list, pixrec, hits, is.hit_total, (uint32_t)capacity, vrow, frow, st);
         dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
         return 0;
     };

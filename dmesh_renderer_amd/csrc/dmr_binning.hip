@@ -231,20 +231,13 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, int ntiles, const uint2* __res
 constexpr int ORDER_BUCKETS = 64;
 __device__ __forceinline__ int order_bucket(uint32_t n) { return ORDER_BUCKETS - 1 - (int)min(n >> 4, (uint32_t)(ORDER_BUCKETS - 1)); }
 
-__global__ void __launch_bounds__(1024)
-k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-             uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered, uint32_t* __restrict__ tile_order) {
-    __shared__ uint32_t wave_sum[16];
-    __shared__ uint32_t carry_s;
-    __shared__ uint32_t bucket[ORDER_BUCKETS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (n + 1023) / 1024;
-    const int begin = min(n, tid * per), end = min(n, begin + per);
-    if (tid < ORDER_BUCKETS) bucket[tid] = 0u;
-    __syncthreads();
-    uint32_t local = 0;
-    for (int i = begin; i < end; i++) { const uint32_t c = tile_count[i]; local += c; atomicAdd(&bucket[order_bucket(c)], 1u); }
-    // inclusive wave scan
+// Both scans are one 1024-thread workgroup (n = B * tiles is small, C4: 8160).  Their time is the chain of
+// dependent global-memory round trips, so a thread fetches its items SCAN_BATCH at a time with independent loads
+// (the first version loaded one item per loop iteration, twice: 16 round trips, 14-17 us).
+constexpr int SCAN_BATCH = 8;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, int tid, uint32_t* wave_sum /*[17]*/) {
+    const int lane = tid & 63, wave = tid >> 6;
     uint32_t incl = local;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -253,12 +246,48 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
     }
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int w = 0; w < 16; w++) { uint32_t t = wave_sum[w]; wave_sum[w] = acc; acc += t; }
-        carry_s = acc;
+    if (tid < 64) {
+        const uint32_t w = tid < 16 ? wave_sum[tid] : 0u;
+        uint32_t wi = w;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            uint32_t o = __shfl_up(wi, d, 64);
+            if (tid >= d) wi += o;
+        }
+        if (tid < 16) wave_sum[tid] = wi - w;
+        if (tid == 15) wave_sum[16] = wi;
     }
-    if (wave == 1) {  // exclusive scan of the bucket sizes: bucket 0 holds the longest lists
+    __syncthreads();
+    return wave_sum[wave] + incl - local;  // total in wave_sum[16]
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+             uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered, uint32_t* __restrict__ tile_order) {
+    __shared__ uint32_t wave_sum[17];
+    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];  // [ORDER_BUCKETS]: empty tiles, behind all the others
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int per = (n + 1023) / 1024;
+    const int begin = min(n, tid * per), end = min(n, begin + per);
+    if (tid <= ORDER_BUCKETS) bucket[tid] = 0u;
+    __syncthreads();
+    uint32_t local = 0;
+    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
+        uint32_t c[SCAN_BATCH];
+#pragma unroll
+        for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_count[i0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < SCAN_BATCH; j++) {
+            local += c[j];
+            // empty tiles (most of a frame) would all hit one LDS counter: they are counted per wave instead
+            const bool empty = i0 + j < end && c[j] == 0u;
+            const uint64_t em = __ballot(empty);
+            if (em && lane == __ffsll((long long)em) - 1) atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
+            if (i0 + j < end && c[j]) atomicAdd(&bucket[order_bucket(c[j])], 1u);
+        }
+    }
+    uint32_t run = block_exclusive_scan(local, tid, wave_sum);
+    if (tid < 64) {  // exclusive scan of the bucket sizes: bucket 0 holds the longest lists, empty tiles come last
         const uint32_t c = bucket[lane];
         uint32_t bi = c;
 #pragma unroll
@@ -267,42 +296,67 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
             if (lane >= d) bi += o;
         }
         bucket[lane] = bi - c;
+        if (lane == 63) bucket[ORDER_BUCKETS] = bi;
     }
     __syncthreads();
-    uint32_t run = wave_sum[wave] + incl - local;
-    for (int i = begin; i < end; i++) {
-        const uint32_t c = tile_count[i];
-        tile_offset[i] = run;
-        tile_cursor[i] = run;
-        run += c;
-        tile_order[atomicAdd(&bucket[order_bucket(c)], 1u)] = (uint32_t)i;
+    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
+        uint32_t c[SCAN_BATCH];
+#pragma unroll
+        for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_count[i0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < SCAN_BATCH; j++) {
+            const bool in = i0 + j < end;
+            if (in) { tile_offset[i0 + j] = run; tile_cursor[i0 + j] = run; }
+            run += c[j];
+            const bool empty = in && c[j] == 0u;
+            const uint64_t em = __ballot(empty);
+            uint32_t ebase = 0;
+            if (em) {
+                const int leader = __ffsll((long long)em) - 1;
+                if (lane == leader) ebase = atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
+                ebase = __shfl(ebase, leader, 64);
+            }
+            if (empty) tile_order[ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)(i0 + j);
+            else if (in) tile_order[atomicAdd(&bucket[order_bucket(c[j])], 1u)] = (uint32_t)(i0 + j);
+        }
     }
-    if (tid == 0) { tile_offset[n] = carry_s; *num_rendered = (int)carry_s; }
+    if (tid == 0) { tile_offset[n] = wave_sum[16]; *num_rendered = (int)wave_sum[16]; }
 }
 
-// exclusive scan of the per-tile hit counts of the forward (u32 offsets, u64 total)
+// exclusive scan of the per-tile hit counts of the forward: every tile's region of the backward's record buffer
+// (u32 offsets; the total is < 2^32 or the backward fails) and the total
 __global__ void __launch_bounds__(1024)
 k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, uint32_t* __restrict__ hit_offset,
             unsigned long long* __restrict__ hit_total) {
-    __shared__ unsigned long long wave_sum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t wave_sum[17];
+    __shared__ unsigned long long s_total;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int per = (n + 1023) / 1024;
     const int begin = min(n, tid * per), end = min(n, begin + per);
-    unsigned long long local = 0;
-    for (int i = begin; i < end; i++) local += tile_hits[i];
-    unsigned long long incl = local;
+    if (tid == 0) s_total = 0ull;
+    uint32_t c[SCAN_BATCH];
+    uint32_t local = 0; unsigned long long wide = 0;
+    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned long long o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
+        for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_hits[i0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < SCAN_BATCH; j++) { local += c[j]; wide += c[j]; }
     }
-    if (lane == 63) wave_sum[wave] = incl;
+    // 64-bit total (overflow check on the host); the offsets themselves wrap harmlessly in that case
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wide += __shfl_xor(wide, d, 64);
+    uint32_t run = block_exclusive_scan(local, tid, wave_sum);
+    if (lane == 0) atomicAdd(&s_total, wide);
+    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
+        if (per > SCAN_BATCH) {
+#pragma unroll
+            for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_hits[i0 + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < SCAN_BATCH; j++) { if (i0 + j < end) hit_offset[i0 + j] = run; run += c[j]; }
+    }
     __syncthreads();
-    unsigned long long base = 0, total = 0;
-    for (int w = 0; w < 16; w++) { if (w < wave) base += wave_sum[w]; total += wave_sum[w]; }
-    unsigned long long run = base + incl - local;
-    for (int i = begin; i < end; i++) { hit_offset[i] = (uint32_t)run; run += tile_hits[i]; }
-    if (tid == 0) { hit_offset[n] = (uint32_t)total; *hit_total = total; }
+    if (tid == 0) { hit_offset[n] = wave_sum[16]; *hit_total = s_total; }
 }
 
 // ---------------------------------------------------------------------------

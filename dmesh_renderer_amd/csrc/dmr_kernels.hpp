@@ -40,8 +40,8 @@ void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* 
 // ---- tri compositing (dmr_tri.hip)
 struct TriImageState {
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits;    // blended (pixel, face) pairs per tile, counted by the forward
-    uint32_t* hit_offset;   // exclusive scan of tile_hits (backward)
+    uint32_t* tile_hits;    // covered (pixel, face) pairs below n_contrib per tile, counted by the forward
+    const uint32_t* hit_offset;     // exclusive scan of tile_hits (k_scan_hits, backward): record regions
     const uint32_t* tile_order;  // all B * gx * gy tiles, longest list first (k_scan_tiles)
 };
 // One blended (pixel, face) pair, written face-major per (tile, chunk, pass) by k_tri_backward_pix and
@@ -53,16 +53,15 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
                         float* out_color, float* out_depth, hipStream_t st);
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
                       hipStream_t st);
+// also zeroes work[0, work_floats) (the packed accumulators)
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
-                             uint32_t capacity, hipStream_t st);
-// the record range [*range_begin, *range_end) is read on the device (clamped to capacity): the launch does not wait
-// for the host to know it; `expected` only sizes the grid
+                             uint32_t capacity, float* work, size_t work_floats, hipStream_t st);
+// the record count min(*hit_total, capacity) is read on the device: the launch does not wait for the host to know it
 void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, const uint32_t* range_begin,
-                              const uint32_t* range_end, uint32_t capacity, uint32_t expected, float* vrow, float* frow,
-                              hipStream_t st);
+                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
+                              uint32_t capacity, float* vrow, float* frow, hipStream_t st);
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
                        float* dL_dvcolor, float* dL_dfopacity, float* dL_dvdepth, float* dL_dfintense,
                        hipStream_t st);

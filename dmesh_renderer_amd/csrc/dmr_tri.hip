@@ -400,7 +400,8 @@ __device__ __forceinline__ void rasterize_faces_counted(const CovRec* __restrict
 
 __global__ void __launch_bounds__(256, DMR_PIX_WAVES)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity) {
+                   float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity,
+                   float* __restrict__ work, uint32_t work_floats) {
     constexpr int CHUNK = BWD_CHUNK;
     constexpr int WORDS = CHUNK / 32;
     static_assert(CHUNK == 128, "one wave scans the face counters, two per lane; 256 threads stage 128 + 128 records");
@@ -413,6 +414,11 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     __shared__ uint32_t s_max_last, s_chunk_hits;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    {   // every block zeroes its slice of the packed gradient accumulators kernel 2 adds into
+        const uint32_t per = (work_floats + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = min(work_floats, blockIdx.x * per), z1 = min(work_floats, z0 + per);
+        for (uint32_t i = z0 + tid; i < z1; i += 256) work[i] = 0.f;
+    }
     // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
     const int tile = (int)p.tile_order[blockIdx.x];
     const int tx = tile % p.gx, ty = (tile / p.gx) % p.gy, b = tile / (p.gx * p.gy);
@@ -426,7 +432,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
 
     const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
     if (begin == end) return;  // uniform
-    uint32_t hit_cursor = p.hit_offset[tile];
+    uint32_t hit_cursor = p.hit_offset[tile];  // the tile's region of the record buffer
     if (hit_cursor == p.hit_offset[tile + 1]) return;  // no pixel of the tile blended anything
 
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
@@ -691,11 +697,10 @@ __attribute__((amdgpu_waves_per_eu(DMR_HITS_WAVES, DMR_HITS_WAVES)))
 #endif
 __global__ void __launch_bounds__(256)
 k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits,
-                    const uint32_t* __restrict__ range_begin, const uint32_t* __restrict__ range_end, uint32_t capacity,
+                    const unsigned long long* __restrict__ hit_total, uint32_t capacity,
                     float* __restrict__ vrow, float* __restrict__ frow) {
-    // records [*range_begin, *range_end) of the tiles of one band (exclusive scan of the per-tile hit counts),
-    // clamped to the buffer capacity while a size guess is being refuted
-    const uint32_t first = min(capacity, *range_begin), nhits = min(capacity, *range_end);
+    // all records; fewer only while a size guess is being refuted
+    const uint32_t first = 0u, nhits = (uint32_t)min((unsigned long long)capacity, *hit_total);
     __shared__ HitsLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t HW = (int64_t)p.H * p.W;
@@ -891,24 +896,24 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
-                             uint32_t capacity, hipStream_t st) {
+                             uint32_t capacity, float* work, size_t work_floats, hipStream_t st) {
     if (r1 <= r0) return;
     TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
-    k_tri_backward_pix<<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity);
+    k_tri_backward_pix<<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity,
+                                                                            work, (uint32_t)work_floats);
 }
 
 void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, const uint32_t* range_begin,
-                              const uint32_t* range_end, uint32_t capacity, uint32_t expected, float* vrow, float* frow,
-                              hipStream_t st) {
-    if (capacity == 0 || expected == 0) return;
+                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
+                              uint32_t capacity, float* vrow, float* frow, hipStream_t st) {
+    if (capacity == 0) return;
     TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     TriParams p = make_params(s, 0, 0, 0, 0, vproj, nullptr, face_list, none);
-    // grid from the host-side estimate of the band's record count; the kernel reads the exact range on the device
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)expected + 2047u) / 2048u, 256u * 16u);  // >= 8 rounds of 64 records per wave
+    // grid from the host-known bound; >= 8 rounds of 64 records per wave
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + 2047u) / 2048u, 256u * 16u);
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
-    k_tri_backward_hits<<<dim3(std::max(1u, blocks)), dim3(256), 0, st>>>(p, pixrec, hits, range_begin, range_end, capacity, vrow, frow);
+    k_tri_backward_hits<<<dim3(std::max(1u, blocks)), dim3(256), 0, st>>>(p, pixrec, hits, hit_total, capacity, vrow, frow);
 }
 
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
