@@ -122,13 +122,14 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     return 0;
 }
 
-// pinned landing pad + event for the 4/8-byte size reads, one per host thread
+// pinned (coherent, device-visible) landing pad the scan kernels write the sizes to, and the event the host
+// waits on; one per host thread
 struct SizeRead { void* slot = nullptr; hipEvent_t ev = nullptr; };
 SizeRead* size_read() {
     thread_local SizeRead sr;
     if (!sr.slot) {
-        if (hipHostMalloc(&sr.slot, 64, hipHostMallocDefault) != hipSuccess) { sr.slot = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&sr.slot, 64, hipHostMallocCoherent) != hipSuccess) { sr.slot = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) return nullptr;
     }
     return &sr;
 }
@@ -174,7 +175,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         dmr::launch_project_verts(*s, ps.vproj, is.mats, st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
-        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, is.tile_order, st);
+        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, is.tile_order, st);
         return 0;
     };
     auto rest = [&](uint64_t capacity) -> int {
@@ -199,7 +200,6 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (it != g_size_cache.end() && it->second.rendered) guess = std::min<uint64_t>(padded(it->second.rendered), 0x7fffffffu);
     }
     if (front()) return 1;
-    DMR_HIP(hipMemcpyAsync(host_R, is.num_rendered, sizeof(int), hipMemcpyDeviceToHost, st));
     DMR_HIP(hipEventRecord(sr->ev, st));
     if (guess && rest(guess)) return 1;
     DMR_HIP(hipEventSynchronize(sr->ev));  // the forward's one host wait (rasterizer_impl.cu:287-292): 4 bytes
@@ -372,8 +372,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         auto it = g_size_cache.find(key);
         if (it != g_size_cache.end() && it->second.hits) guess = std::min<uint64_t>(padded(it->second.hits), 0xfffffffeull);
     }
-    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, st);
-    DMR_HIP(hipMemcpyAsync(host_total, is.hit_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, host_total, st);
     DMR_HIP(hipEventRecord(sr->ev, st));
     if (guess && rest(guess)) return 1;
     DMR_HIP(hipEventSynchronize(sr->ev));

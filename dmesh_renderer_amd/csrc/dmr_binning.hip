@@ -263,7 +263,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, int tid
 
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-             uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered, uint32_t* __restrict__ tile_order) {
+             uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered, int* __restrict__ host_num_rendered,
+             uint32_t* __restrict__ tile_order) {
     __shared__ uint32_t wave_sum[17];
     __shared__ uint32_t bucket[ORDER_BUCKETS + 1];  // [ORDER_BUCKETS]: empty tiles, behind all the others
     const int tid = threadIdx.x, lane = tid & 63;
@@ -320,14 +321,15 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
             else if (in) tile_order[atomicAdd(&bucket[order_bucket(c[j])], 1u)] = (uint32_t)(i0 + j);
         }
     }
-    if (tid == 0) { tile_offset[n] = wave_sum[16]; *num_rendered = (int)wave_sum[16]; }
+    // host_num_rendered: pinned host memory, read by the host after the event recorded behind this kernel
+    if (tid == 0) { tile_offset[n] = wave_sum[16]; *num_rendered = (int)wave_sum[16]; *host_num_rendered = (int)wave_sum[16]; }
 }
 
 // exclusive scan of the per-tile hit counts of the forward: every tile's region of the backward's record buffer
 // (u32 offsets; the total is < 2^32 or the backward fails) and the total
 __global__ void __launch_bounds__(1024)
 k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, uint32_t* __restrict__ hit_offset,
-            unsigned long long* __restrict__ hit_total) {
+            unsigned long long* __restrict__ hit_total, unsigned long long* __restrict__ host_hit_total) {
     __shared__ uint32_t wave_sum[17];
     __shared__ unsigned long long s_total;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -356,7 +358,7 @@ k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, uint32_t* __restrict_
         for (int j = 0; j < SCAN_BATCH; j++) { if (i0 + j < end) hit_offset[i0 + j] = run; run += c[j]; }
     }
     __syncthreads();
-    if (tid == 0) { hit_offset[n] = wave_sum[16]; *hit_total = s_total; }
+    if (tid == 0) { hit_offset[n] = wave_sum[16]; *hit_total = s_total; *host_hit_total = s_total; }
 }
 
 // ---------------------------------------------------------------------------
@@ -530,15 +532,15 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
 }
 
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
-                       int* num_rendered, uint32_t* tile_order, hipStream_t st) {
+                       int* num_rendered, int* host_num_rendered, uint32_t* tile_order, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
-    k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered, tile_order);
+    k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered, host_num_rendered, tile_order);
 }
 
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
-                      hipStream_t st) {
+                      unsigned long long* host_hit_total, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
-    k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, hit_offset, hit_total);
+    k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, hit_offset, hit_total, host_hit_total);
 }
 
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
