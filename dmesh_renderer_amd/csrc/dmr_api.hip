@@ -46,7 +46,7 @@ struct Carver {
 };
 
 struct PointState { float4* vproj; };
-struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* tiles_touched; };
+struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* tiles_touched; void* facerec; void* colrec; void* tetrec; };
 struct ImageState {
     uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_cursor; int* num_rendered;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
@@ -57,11 +57,17 @@ struct ImageState {
 struct BinningState { uint64_t* keys; uint32_t* face_list; };
 
 size_t carve_point(void* b, size_t BP, PointState& s) { Carver c(b); s.vproj = c.take<float4>(BP); return c.off; }
-size_t carve_face(void* b, size_t BF, bool tet, FaceState& s) {
+size_t carve_face(void* b, size_t BF, size_t F, size_t T, bool tet, FaceState& s) {
     Carver c(b);
     s.rect = c.take<uint2>(BF); s.key_depth = c.take<float>(BF);
     s.max_depth = tet ? c.take<float>(BF) : nullptr;
     s.tiles_touched = c.take<uint32_t>(BF);
+    s.facerec = s.colrec = s.tetrec = nullptr;
+    if (tet) {  // packed march records (view independent)
+        s.facerec = c.take<char>(F * dmr::tet_facerec_bytes());
+        s.colrec = c.take<char>(F * dmr::tet_colrec_bytes());
+        s.tetrec = c.take<int4>(T);
+    }
     return c.off;
 }
 size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, ImageState& s) {
@@ -160,11 +166,11 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
                 const std::function<void(const BinningState&)>& render) {
     PointState tp; FaceState tf; ImageState ti;
     void* pb = alloc(ctx, DMR_BUF_POINT, carve_point(nullptr, d.BP, tp));
-    void* fb = alloc(ctx, DMR_BUF_FACE, carve_face(nullptr, d.BF, tet, tf));
+    void* fb = alloc(ctx, DMR_BUF_FACE, carve_face(nullptr, d.BF, (size_t)s->F, (size_t)s->T, tet, tf));
     void* ib = alloc(ctx, DMR_BUF_IMAGE, carve_image(nullptr, (size_t)s->B, (size_t)d.ntiles, d.npix, tet, ti));
     if (!pb || !fb || !ib) return fail("scratch allocation failed");
     carve_point(pb, d.BP, ps);
-    carve_face(fb, d.BF, tet, fs);
+    carve_face(fb, d.BF, (size_t)s->F, (size_t)s->T, tet, fs);
     carve_image(ib, (size_t)s->B, (size_t)d.ntiles, d.npix, tet, is);
     SizeRead* sr = size_read();
     if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
@@ -331,7 +337,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     if (!point_buf || !face_buf || !binning_buf || !image_buf || !alloc) return fail("null scratch buffer");
     PointState ps; FaceState fs; ImageState is; BinningState bs;
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
-    carve_face(const_cast<void*>(face_buf), d.BF, false, fs);
+    carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, false, fs);
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, false, is);
     carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, bs);
 
@@ -402,8 +408,9 @@ int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, floa
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
         dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
-                               is.last_face, is.last_tet, is.is_active};
+                               is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec};
         const dmr_scene sc = canonical(s, is.mats);
+        dmr::launch_tet_prep(sc, img, st);
         dmr::launch_tet_first_intersect(sc, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
                                         bs.face_list, img, st);
         dmr::launch_tet_forward(sc, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
@@ -420,11 +427,12 @@ int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     if (s->P > 0) DMR_HIP(hipMemsetAsync(dL_dvcolor, 0, sizeof(float) * 3 * (size_t)s->P, st));
     if (s->F > 0) DMR_HIP(hipMemsetAsync(dL_dfopacity, 0, sizeof(float) * (size_t)s->F, st));
     if (s->P == 0 || s->F == 0) return 0;
-    if (!image_buf) return fail("null scratch buffer");
-    ImageState is;
+    if (!image_buf || !face_buf) return fail("null scratch buffer");
+    ImageState is; FaceState fs;
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, true, is);
+    carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, true, fs);
     dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
-                           is.last_face, is.last_tet, is.is_active};
+                           is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec};
     const dmr_scene sc = canonical(s, is.mats);
     dmr::launch_tet_backward(sc, d.gx, d.gy, d.r0, d.r1, img, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, st);
     DMR_HIP(hipGetLastError());
@@ -457,7 +465,7 @@ int64_t dmr_export(const dmr_scene* s, int is_tet, int num_rendered, const char*
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PointState ps; FaceState fs; ImageState is; BinningState bs;
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
-    carve_face(const_cast<void*>(face_buf), d.BF, is_tet != 0, fs);
+    carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, is_tet != 0, fs);
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, is_tet != 0, is);
     carve_binning(const_cast<void*>(binning_buf), (size_t)std::max(0, num_rendered), bs);
     const std::string n(name);

@@ -71,7 +71,12 @@ void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow,
 struct TetImageState {
     float* final_log_T; float* final_prev_log_T; uint32_t* n_contrib;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
+    void* facerec; void* colrec; void* tetrec;  // packed march records (dmr_tet.hip), in the face buffer
 };
+size_t tet_facerec_bytes();
+size_t tet_colrec_bytes();
+// builds the packed march records from the scene (every forward call)
+void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st);
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
                                 const float* max_depth, const uint32_t* tile_offset, const uint32_t* face_list,
                                 TetImageState img, hipStream_t st);

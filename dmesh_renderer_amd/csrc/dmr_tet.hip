@@ -18,14 +18,97 @@ constexpr int FI_CHUNK = 256;
 struct alignas(16) HitRec { float p0[3], p1[3], p2[3]; float min_depth, max_depth; int face; };
 static_assert(sizeof(HitRec) == 48, "HitRec");
 
+struct alignas(16) TetFaceRec { float p0[3], p1[3], p2[3], n[3]; int ft0, ft1; float opacity; int pad; };
+static_assert(sizeof(TetFaceRec) == 64, "TetFaceRec");
+struct alignas(16) TetColRec { float c0[3], c1[3], c2[3]; int v0, v1, v2; };
+static_assert(sizeof(TetColRec) == 48, "TetColRec");
+
 struct TetParams {
     int B, P, F, W, H, gx, gy, r0;
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* mv; const float* proj; const float* inv_mv; const float* inv_proj;
     const float* faces_intense; const float* bg;
     const int* tets; const int* face_tets; const int* tet_faces;
+    const TetFaceRec* facerec; const TetColRec* colrec; const int4* tetrec;
     TetImageState img;
 };
+
+// ---------------------------------------------------------------------------
+// Packed march records, rebuilt by every forward call (geometry and colours are inputs) and kept in the
+// face buffer for the backward.  A march step of the reference (cuda_renderer/forward.cu:704-767) is a
+// chain of narrow dependent gathers: tet_faces -> faces -> verts for four faces, tets -> verts for the
+// centre, then four normalised outward normals (sqrt + divide each).  Everything that does not depend
+// on the ray is hoisted here, with the reference's arithmetic, so the decisions stay bit-identical:
+//   TetFaceRec : the three vertices, the UNIT normal before orientation, face_tets, opacity -- one 64-byte line
+//   TetColRec  : the three vertex colours
+//   tetrec     : the four faces of a tet, bit 31 set where tet_face_outward_normal flips the unit normal
+//                (dot(n, centre - p0) > 0, cuda_renderer/auxiliary.h:386-392); dot(-n, d) == -dot(n, d) exactly.
+// A step is then tetrec -> 3 x TetFaceRec: two dependent levels of 16-byte loads.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_tet_prep_faces(int F, const float* __restrict__ verts, const int* __restrict__ faces,
+                 const float* __restrict__ verts_color, const float* __restrict__ faces_opacity,
+                 const int* __restrict__ face_tets, TetFaceRec* __restrict__ facerec, TetColRec* __restrict__ colrec) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
+    const V3 p0 = load_v3(verts, v0), p1 = load_v3(verts, v1), p2 = load_v3(verts, v2);
+    V3 n = cross(p1 - p0, p2 - p0);  // cuda_renderer/auxiliary.h:375-384
+    float n_norm = sqrtf(dot(n, n));
+    n_norm = fmaxf(n_norm, 0.0001f);
+    n = n / n_norm;
+    TetFaceRec r;
+    r.p0[0] = p0.x; r.p0[1] = p0.y; r.p0[2] = p0.z;
+    r.p1[0] = p1.x; r.p1[1] = p1.y; r.p1[2] = p1.z;
+    r.p2[0] = p2.x; r.p2[1] = p2.y; r.p2[2] = p2.z;
+    r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
+    r.ft0 = face_tets[2 * f]; r.ft1 = face_tets[2 * f + 1];
+    r.opacity = faces_opacity[f]; r.pad = 0;
+    facerec[f] = r;
+    const V3 c0 = load_v3(verts_color, v0), c1 = load_v3(verts_color, v1), c2 = load_v3(verts_color, v2);
+    TetColRec c;
+    c.c0[0] = c0.x; c.c0[1] = c0.y; c.c0[2] = c0.z;
+    c.c1[0] = c1.x; c.c1[1] = c1.y; c.c1[2] = c1.z;
+    c.c2[0] = c2.x; c.c2[1] = c2.y; c.c2[2] = c2.z;
+    c.v0 = v0; c.v1 = v1; c.v2 = v2;
+    colrec[f] = c;
+}
+
+__global__ void __launch_bounds__(256)
+k_tet_prep_tets(int T, int F, const float* __restrict__ verts, const int* __restrict__ tets,
+                const int* __restrict__ tet_faces, const TetFaceRec* __restrict__ facerec, int4* __restrict__ tetrec) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const V3 center = tet_center(verts, tets, t);
+    int f[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f[i] = tet_faces[4 * t + i];
+        if (f[i] >= 0 && f[i] < F) {
+            const TetFaceRec& r = facerec[f[i]];
+            const V3 n = {r.n[0], r.n[1], r.n[2]}, p0 = {r.p0[0], r.p0[1], r.p0[2]};
+            if (dot(n, center - p0) > 0.0f) f[i] |= (int)0x80000000;
+        }
+    }
+    tetrec[t] = make_int4(f[0], f[1], f[2], f[3]);
+}
+
+__device__ __forceinline__ TetFaceRec load_facerec(const TetFaceRec* __restrict__ a, int f) {
+    const float4* q = reinterpret_cast<const float4*>(a + f);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    TetFaceRec r;
+    r.p0[0] = q0.x; r.p0[1] = q0.y; r.p0[2] = q0.z; r.p1[0] = q0.w;
+    r.p1[1] = q1.x; r.p1[2] = q1.y; r.p2[0] = q1.z; r.p2[1] = q1.w;
+    r.p2[2] = q2.x; r.n[0] = q2.y; r.n[1] = q2.z; r.n[2] = q2.w;
+    r.ft0 = __float_as_int(q3.x); r.ft1 = __float_as_int(q3.y); r.opacity = q3.z; r.pad = 0;
+    return r;
+}
+
+// dot(outward normal of `face` as seen from `tet`, d): flip = bit 31 of the tet's record entry
+__device__ __forceinline__ float oriented_dot(const TetFaceRec& r, bool flip, V3 d) {
+    const float v = dot(V3{r.n[0], r.n[1], r.n[2]}, d);
+    return flip ? -v : v;
+}
 
 __global__ void __launch_bounds__(256)
 k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const float* __restrict__ max_depth,
@@ -77,11 +160,16 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
     if (!inside) return;
     int ft = -1;
     if (ff >= 0) {
+        const TetFaceRec fr = load_facerec(p.facerec, ff);
         for (int i = 0; i < 2; i++) {
-            const int tet_id = p.face_tets[2 * ff + i];
+            const int tet_id = i == 0 ? fr.ft0 : fr.ft1;
             if (tet_id < 0) continue;
-            const V3 n = tet_face_outward_normal(p.verts, p.faces, p.tets, ff, tet_id);
-            if (dot(n, rd) < 0.0f) ft = tet_id;
+            const int4 tr = p.tetrec[tet_id];
+            const int e[4] = {tr.x, tr.y, tr.z, tr.w};
+            bool flip = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if ((e[q] & 0x7fffffff) == ff) flip = e[q] < 0;
+            if (oriented_dot(fr, flip, rd) < 0.0f) ft = tet_id;
         }
     }
     p.img.first_face[bpix] = ff;
@@ -90,8 +178,8 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
 
 __device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int face, float& rt, float& iu, float& iv) {
     V3 tuv = {0, 0, 0};
-    ray_tri_hit(ro, rd, load_v3(p.verts, p.faces[3 * face]), load_v3(p.verts, p.faces[3 * face + 1]),
-                load_v3(p.verts, p.faces[3 * face + 2]), tuv);
+    const TetFaceRec r = load_facerec(p.facerec, face);
+    ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]}, {r.p2[0], r.p2[1], r.p2[2]}, tuv);
     rt = tuv.x; iu = tuv.y; iv = tuv.z;
 }
 
@@ -101,44 +189,47 @@ __device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int f
 template <bool FWD>
 __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet,
                                            float& curr_rt, float& curr_iu, float& curr_iv) {
-    int others[3];
+    const int4 tr = p.tetrec[curr_tet];
+    const int e[4] = {tr.x, tr.y, tr.z, tr.w};
+    int others[3] = {0, 0, 0};
+    bool oflip[3] = {false, false, false};
     int cnt = 0;
-    bool ok = true;
+    bool cur_flip = false;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int tf = p.tet_faces[4 * curr_tet + i];
-        if (tf == curr_face) continue;
-        if (cnt < 3) others[cnt] = tf;
+        const int tf = e[i] & 0x7fffffff;
+        if (tf == curr_face) { cur_flip = e[i] < 0; continue; }
+        if (cnt < 3) { others[cnt] = tf; oflip[cnt] = e[i] < 0; }
         cnt++;
     }
     if (cnt != 3) return false;
-    const V3 center = tet_center(p.verts, p.tets, curr_tet);
-    const V3 ncur = face_outward_normal(load_v3(p.verts, p.faces[3 * curr_face]), load_v3(p.verts, p.faces[3 * curr_face + 1]),
-                                        load_v3(p.verts, p.faces[3 * curr_face + 2]), center);
-    const float dcur = dot(ncur, rd);
+    // the three candidate faces: independent 64-byte records, all in flight together
+    // (a face id outside [0, F) -- malformed tet_faces -- never hits instead of reading out of bounds)
+    const bool oval[3] = {(unsigned)others[0] < (unsigned)p.F, (unsigned)others[1] < (unsigned)p.F, (unsigned)others[2] < (unsigned)p.F};
+    const TetFaceRec r0 = load_facerec(p.facerec, oval[0] ? others[0] : 0);
+    const TetFaceRec r1 = load_facerec(p.facerec, oval[1] ? others[1] : 0);
+    const TetFaceRec r2 = load_facerec(p.facerec, oval[2] ? others[2] : 0);
+    const TetFaceRec rc = load_facerec(p.facerec, curr_face);
+    bool ok = true;
+    const float dcur = oriented_dot(rc, cur_flip, rd);
     if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
-    int nf = -1, ncnt = 0;
+    int nf = -1, ncnt = 0, nft0 = -1, nft1 = -1;
     float nrt = 0, niu = 0, niv = 0;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
+        const TetFaceRec& r = i == 0 ? r0 : (i == 1 ? r1 : r2);
         V3 tuv;
-        const int of = others[i];
-        const V3 a0 = load_v3(p.verts, p.faces[3 * of]), a1 = load_v3(p.verts, p.faces[3 * of + 1]),
-                 a2 = load_v3(p.verts, p.faces[3 * of + 2]);
-        const bool hit = ray_tri_hit(ro, rd, a0, a1, a2, tuv);
-        const V3 n = face_outward_normal(a0, a1, a2, center);
-        const float dn = dot(n, rd);
-        if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) { nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; ncnt++; }
+        const bool hit = ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
+                                     {r.p2[0], r.p2[1], r.p2[2]}, tuv) && oval[i];
+        const float dn = oriented_dot(r, oflip[i], rd);
+        if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) {
+            nf = others[i]; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; ncnt++;
+        }
     }
     if (ncnt != 1 || !ok) return false;
     int nt = -1;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int t = p.face_tets[2 * nf + i];
-        if (t == curr_tet || t == -1) continue;
-        nt = t;
-        break;
-    }
+    if (!(nft0 == curr_tet || nft0 == -1)) nt = nft0;
+    else if (!(nft1 == curr_tet || nft1 == -1)) nt = nft1;
     curr_face = nf; curr_tet = nt; curr_rt = nrt; curr_iu = niu; curr_iv = niv;
     return true;
 }
@@ -168,9 +259,9 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     bool active = false;
     uint32_t n_contrib = 0;
     while (!done) {
-        const V3 c0 = load_v3(p.verts_color, p.faces[3 * curr_face]);
-        const V3 c1 = load_v3(p.verts_color, p.faces[3 * curr_face + 1]);
-        const V3 c2 = load_v3(p.verts_color, p.faces[3 * curr_face + 2]);
+        const float4* cq = reinterpret_cast<const float4*>(p.colrec + curr_face);
+        const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2];
+        const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
         V3 col = (c0 + (c1 - c0) * curr_iu + (c2 - c0) * curr_iv);  // Q21
         const float opacity = p.faces_opacity[curr_face];
         const float intense = p.faces_intense[(int64_t)b * p.F + curr_face];
@@ -216,14 +307,17 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
 // Gradient accumulation of the tet backward.  The reference issues 10 scattered global atomics per
 // (pixel, face) (cuda_renderer/backward.cu:353-360); at C3 that is 240 M memory-side requests (19.6 ms
 // measured on MI355X).  The pixels of a 16x16 tile march through nearly the same faces, so the tile
-// first sums per face in an LDS hash table (key = face id, 10 float cells, ds_cmpst + ds_add_f32) and
-// touches global memory once per (tile, face): 3 vertex-colour rows + the opacity.  A full table or a
-// long probe sequence falls back to the direct atomics.
+// first sums per face in an LDS hash table (key = face id, 10 cells, ds_cmpst + ds_add_f64) and touches
+// global memory once per (tile, face): 3 vertex-colour rows + the opacity.  A full table or a long probe
+// sequence falls back to the direct atomics.  The cells are DOUBLES because of the atomic's rate, not its
+// precision: ds_add_f32 retires one lane per ~3 cycles per CU, ds_add_f64 ten times that
+// (scripts/micro/lds_atomics.hip: 194 vs 20 cycles per conflict-free wave instruction), and this kernel was
+// bound by exactly those adds (10 per marched face and pixel).
 constexpr int TET_TBL = 512;     // slots (power of two)
 constexpr int TET_PROBES = 8;
 
 struct TetAccum {
-    int* key; float (*val)[TET_TBL];
+    int* key; double (*val)[TET_TBL];
     __device__ __forceinline__ int find(int face) const {
         uint32_t slot = ((uint32_t)face * 2654435761u) >> 23;  // top 9 bits
         for (int i = 0; i < TET_PROBES; i++) {
@@ -239,12 +333,12 @@ __global__ void __launch_bounds__(256)
 k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                float* __restrict__ dL_dvcolor, float* __restrict__ dL_dfopacity) {
     __shared__ int s_key[TET_TBL];
-    __shared__ float s_val[10][TET_TBL];
+    __shared__ double s_val[10][TET_TBL];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < TET_TBL; i += 256) {
         s_key[i] = -1;
 #pragma unroll
-        for (int c = 0; c < 10; c++) s_val[c][i] = 0.f;
+        for (int c = 0; c < 10; c++) s_val[c][i] = 0.0;
     }
     __syncthreads();
     const TetAccum acc{s_key, s_val};
@@ -287,8 +381,10 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
         float last_alpha = 0.f, lc0 = 0, lc1 = 0, lc2 = 0, ar0 = 0, ar1 = 0, ar2 = 0, last_depth = 0.f, ard = 0.f;
         bool first_iter = true, done = false;
         while (!done) {
-            const int v0 = p.faces[3 * curr_face], v1 = p.faces[3 * curr_face + 1], v2 = p.faces[3 * curr_face + 2];
-            const V3 c0 = load_v3(p.verts_color, v0), c1 = load_v3(p.verts_color, v1), c2 = load_v3(p.verts_color, v2);
+            const float4* cq = reinterpret_cast<const float4*>(p.colrec + curr_face);
+            const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2];
+            const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
+            const int v0 = __float_as_int(cq2.y), v1 = __float_as_int(cq2.z), v2 = __float_as_int(cq2.w);
             const float i0 = 1.0f - curr_iu - curr_iv, i1 = curr_iu, i2 = curr_iv;
             V3 col = (i0 * c0) + (i1 * c1) + (i2 * c2);  // Q21
             const float opacity = p.faces_opacity[curr_face];
@@ -326,7 +422,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
             const int slot = acc.find(curr_face);
             if (slot >= 0) {
 #pragma unroll
-                for (int c = 0; c < 10; c++) atomicAdd(&s_val[c][slot], g[c]);
+                for (int c = 0; c < 10; c++) atomicAdd(&s_val[c][slot], (double)g[c]);
             } else {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -351,7 +447,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
         const int slot = s0 + (tid >> 4);
         const int face = s_key[slot];
         if (face < 0 || sub > 9) continue;
-        const float v = s_val[sub][slot];
+        const float v = (float)s_val[sub][slot];
         if (sub < 9) atomicAdd(&dL_dvcolor[3 * p.faces[3 * face + sub / 3] + sub % 3], v);
         else atomicAdd(&dL_dfopacity[face], v);
     }
@@ -364,8 +460,25 @@ static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImag
     p.mv = s.mv_mats; p.proj = s.proj_mats; p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats;
     p.faces_intense = s.faces_intense; p.bg = s.background;
     p.tets = s.tets; p.face_tets = s.face_tets; p.tet_faces = s.tet_faces;
+    p.facerec = reinterpret_cast<const TetFaceRec*>(img.facerec);
+    p.colrec = reinterpret_cast<const TetColRec*>(img.colrec);
+    p.tetrec = reinterpret_cast<const int4*>(img.tetrec);
     p.img = img;
     return p;
+}
+
+size_t tet_facerec_bytes() { return sizeof(TetFaceRec); }
+size_t tet_colrec_bytes() { return sizeof(TetColRec); }
+
+void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st) {
+    if (s.F > 0)
+        k_tet_prep_faces<<<dim3((unsigned)((s.F + 255) / 256)), dim3(256), 0, st>>>(
+            s.F, s.verts, s.faces, s.verts_color, s.faces_opacity, s.face_tets,
+            reinterpret_cast<TetFaceRec*>(img.facerec), reinterpret_cast<TetColRec*>(img.colrec));
+    if (s.T > 0)
+        k_tet_prep_tets<<<dim3((unsigned)((s.T + 255) / 256)), dim3(256), 0, st>>>(
+            s.T, s.F, s.verts, s.tets, s.tet_faces, reinterpret_cast<const TetFaceRec*>(img.facerec),
+            reinterpret_cast<int4*>(img.tetrec));
 }
 
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,

@@ -18,6 +18,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
             if (MODE == 0) atomicAdd(&sf[a], 1.0f);
             else if (MODE == 1) atomicAdd(&su[a], 1u);
             else if (MODE == 2) atomicOr(&su[a], 1u << (lane & 31));
+            else if (MODE == 4) atomicAdd(reinterpret_cast<unsigned long long*>(sf) + (a >> 1), 1ull);
+            else if (MODE == 5) atomicAdd(reinterpret_cast<double*>(sf) + (a >> 1), 1.0);
             else sf[a] = (float)it;  // plain store for reference
         }
     }
@@ -44,5 +46,7 @@ int main() {
     run<1, 0>("ds_add_u32 distinct");  run<1, 1>("ds_add_u32 8 lanes/address");  run<1, 2>("ds_add_u32 64 lanes/address");
     run<2, 0>("ds_or_b32  distinct");  run<2, 1>("ds_or_b32  8 lanes/address");  run<2, 2>("ds_or_b32  64 lanes/address");
     run<3, 0>("ds_write_b32 distinct");
+    run<4, 0>("ds_add_u64 distinct");  run<4, 1>("ds_add_u64 8 lanes/address");  run<4, 2>("ds_add_u64 64 lanes/address");
+    run<5, 0>("ds_add_f64 distinct");  run<5, 1>("ds_add_f64 8 lanes/address");
     return 0;
 }
