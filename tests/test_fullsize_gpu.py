@@ -1,0 +1,159 @@
+"""Full-size (BASELINE configs C3 / C4) checks through size-independent properties, plus the host-side contracts
+that only show at scale or over repeated calls.  The oracle finishes C3/C4 in a fraction of a second on the
+box's host cores, so the direct comparison is run too.
+
+Properties:
+  * per-tile lists are sorted by (depth bits, face id)           -- the reference's stable radix sort (Q6)
+  * the per-tile ranges partition [0, R) in tile order           -- identifyTileRanges
+  * forward twice -> bit-identical images and n_contrib          -- no order dependence in the forward
+  * backward is linear in the upstream gradient                  -- g(2 dL) == 2 g(dL)
+  * backward twice from one forward -> same gradients            -- no state left behind by a backward
+  * two tile-row bands compose to the full image and gradient    -- the multi-GPU shard is exact
+  * matrices handed over as transposed views == contiguous ones  -- dmr_scene.mats_transposed
+"""
+import numpy as np
+import pytest
+import torch as th
+
+from dmesh_renderer_amd import scenes
+from util import c_args, rel_err, upstream_grads
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+GRAD_TOL = 1e-4
+NAMES = ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")
+
+
+@pytest.fixture(scope="module")
+def c4(hip_device):
+    from dmesh_renderer_amd import _C
+    cfg = scenes.CONFIGS["C4"]
+    d = scenes.make("C4")
+    args = c_args(d, hip_device)
+    gc, gd = upstream_grads(cfg.B, cfg.H, cfg.W)
+    out = _C.render_tris(*args, cfg.H, cfg.W)
+    return dict(cfg=cfg, d=d, args=args, gc=gc.to(hip_device), gd=gd.to(hip_device), out=out)
+
+
+def test_c4_lists_sorted_and_ranges_partition(c4):
+    from dmesh_renderer_amd import _C
+    cfg, args, out = c4["cfg"], c4["args"], c4["out"]
+    R, bufs = out[0], out[3:7]
+    ex = lambda n, dt: _C.export(n, args, False, R, bufs, cfg.H, cfg.W, dt)
+    ranges = ex("ranges", th.int32).view(-1, 2).long()
+    face_list = ex("face_list", th.int32).long()
+    key_depth = ex("key_depth", th.float32)
+    assert face_list.numel() == R and R > 500_000
+    n = ranges[:, 1] - ranges[:, 0]
+    busy = n > 0
+    assert int(n.sum()) == R
+    # busy tiles partition [0, R) in tile order
+    starts = ranges[busy, 0]
+    assert int(starts[0]) == 0 and th.equal(starts[1:], ranges[busy, 1][:-1]) and int(ranges[busy, 1][-1]) == R
+    # sorted by (depth bits, face id) inside every tile: compare neighbours, masking tile boundaries
+    bits = key_depth.view(th.int32)[face_list].long()  # key depths are in [0, 1]: the bit pattern orders like the value
+    key = bits * (1 << 32) + face_list
+    tile_of = th.repeat_interleave(th.arange(ranges.shape[0], device=key.device)[busy], n[busy])
+    same = tile_of[1:] == tile_of[:-1]
+    assert bool((key[1:][same] > key[:-1][same]).all())
+
+
+def test_c4_forward_repeatable_and_matches_oracle(c4, oracle):
+    from dmesh_renderer_amd import _C
+    cfg, args, out = c4["cfg"], c4["args"], c4["out"]
+    again = _C.render_tris(*args, cfg.H, cfg.W)
+    assert again[0] == out[0] and th.equal(again[1], out[1]) and th.equal(again[2], out[2])
+    sc = oracle.scene_from_module_inputs(c4["d"], cfg.H, cfg.W)
+    ocolor, odepth, ost = oracle.tri_forward(sc)
+    assert out[0] == ost.num_rendered
+    assert np.abs(out[1].cpu().numpy() - ocolor).max() <= FWD_TOL
+    assert np.abs(out[2].cpu().numpy() - odepth).max() <= FWD_TOL
+    og = oracle.tri_backward(sc, ost, c4["gc"].cpu().numpy(), c4["gd"].cpu().numpy())
+    g = _C.render_tris_backward(*args, c4["gc"], c4["gd"], out[0], *out[3:7])
+    for got, k in zip(g, NAMES):
+        assert rel_err(got.cpu().numpy(), og[k]) <= GRAD_TOL, k
+
+
+def test_c4_backward_linear_and_repeatable(c4):
+    from dmesh_renderer_amd import _C
+    args, out = c4["args"], c4["out"]
+    g1 = _C.render_tris_backward(*args, c4["gc"], c4["gd"], out[0], *out[3:7])
+    g1b = _C.render_tris_backward(*args, c4["gc"], c4["gd"], out[0], *out[3:7])
+    g2 = _C.render_tris_backward(*args, 2.0 * c4["gc"], 2.0 * c4["gd"], out[0], *out[3:7])
+    for a, b, c, k in zip(g1, g1b, g2, NAMES):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 1e-5, k      # float atomics: order may differ
+        assert rel_err(c.cpu().numpy(), 2.0 * a.cpu().numpy()) <= 1e-5, k
+
+
+def test_c4_bands_compose(c4):
+    from dmesh_renderer_amd import _C
+    cfg, args, out = c4["cfg"], c4["args"], c4["out"]
+    gfull = _C.render_tris_backward(*args, c4["gc"], c4["gd"], out[0], *out[3:7])
+    gy = (cfg.H + 15) // 16
+    cuts = (0, gy // 3, gy)  # uneven on purpose
+    color = th.zeros_like(out[1]); depth = th.zeros_like(out[2])
+    gsum = [th.zeros_like(t) for t in gfull]
+    rsum = 0
+    for rows in zip(cuts[:-1], cuts[1:]):
+        o = _C.render_tris(*args, cfg.H, cfg.W, rows=rows)
+        rsum += o[0]
+        color += o[1]; depth += o[2]
+        for a, b in zip(gsum, _C.render_tris_backward(*args, c4["gc"], c4["gd"], o[0], *o[3:7], rows=rows)):
+            a += b
+    assert rsum == out[0]
+    assert th.equal(color, out[1]) and th.equal(depth, out[2])
+    for a, b, k in zip(gsum, gfull, NAMES):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, k
+
+
+def test_matrix_layouts_agree(hip_device):
+    """The wrapper hands mv/proj as .transpose(1, 2) views and their th.inverse (strides (16, 1, 4)); the library reads
+    that storage in place.  Contiguous copies and a mix of both must give bit-identical images."""
+    from dmesh_renderer_amd import _C
+    B, H, W = 2, 200, 328
+    d = scenes.layered_sheets(3, 12, B, H, W, seed=1)
+    args = c_args(d, hip_device)
+    assert not args[5].is_contiguous() and args[5].transpose(1, 2).is_contiguous()
+    ref = _C.render_tris(*args, H, W)
+    for which in ((5, 6, 7, 8), (5, 8), (6, 7)):
+        a = list(args)
+        for i in which:
+            a[i] = a[i].contiguous()
+        o = _C.render_tris(*a, H, W)
+        assert o[0] == ref[0] and th.equal(o[1], ref[1]) and th.equal(o[2], ref[2])
+    # a layout that is neither (sliced storage) goes through one copy
+    a = list(args)
+    a[5] = th.cat([a[5].contiguous(), a[5].contiguous()], dim=2)[:, :, :4]
+    o = _C.render_tris(*a, H, W)
+    assert th.equal(o[1], ref[1])
+    gc, gd = upstream_grads(B, H, W)
+    g0 = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), ref[0], *ref[3:7])
+    ac = [t.contiguous() if i in (5, 6, 7, 8) else t for i, t in enumerate(args)]
+    g1 = _C.render_tris_backward(*ac, gc.to(hip_device), gd.to(hip_device), ref[0], *ref[3:7])
+    for x, y in zip(g0, g1):
+        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) <= 1e-5
+
+
+def test_c3_tet_matches_oracle_and_repeats(hip_device, oracle):
+    from dmesh_renderer_amd import _C
+    H = W = 800
+    d = scenes.kuhn_tets(16, 1, H, W)
+    args = c_args(d, hip_device, tet=True)
+    gc, gd = upstream_grads(1, H, W)
+    out = _C.render_tets(*args, H, W, 0)
+    again = _C.render_tets(*args, H, W, 0)
+    assert th.equal(out[0], again[0]) and th.equal(out[1], again[1]) and th.equal(out[2], again[2])
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    ocolor, odepth, oactive, ost = oracle.tet_forward(sc)
+    assert np.array_equal(out[2].cpu().numpy(), oactive)
+    assert np.abs(out[0].cpu().numpy() - ocolor).max() <= FWD_TOL
+    assert np.abs(out[1].cpu().numpy() - odepth).max() <= FWD_TOL
+    np.testing.assert_array_equal(_C.export("first_face", args, True, 0, out[3:7], H, W, th.int32).cpu().numpy(), ost.get("first_face"))
+    np.testing.assert_array_equal(_C.export("last_face", args, True, 0, out[3:7], H, W, th.int32).cpu().numpy(), ost.get("last_face"))
+    og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+    g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *out[3:7])
+    g2 = _C.render_tets_backward(*args, 2.0 * gc.to(hip_device), 2.0 * gd.to(hip_device), *out[3:7])
+    for got, twice, k in zip(g, g2, ("verts_color", "faces_opacity")):
+        assert rel_err(got.cpu().numpy(), og[k]) <= GRAD_TOL, k
+        assert rel_err(twice.cpu().numpy(), 2.0 * got.cpu().numpy()) <= 1e-5, k
