@@ -606,14 +606,39 @@ __device__ __forceinline__ F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y,
 __device__ __forceinline__ F3 load3(const float* __restrict__ a, int id) { return {a[3 * id], a[3 * id + 1], a[3 * id + 2]}; }
 }  // namespace fm
 
-constexpr int STAGE_SEGS = 16;   // segment totals staged per wave before a flush: 16 x (3 vertex rows + 1 face row) = 64 refs
+constexpr int STAGE_SEGS = 16;   // segment totals handled per round and wave: 16 x (3 vertex rows + 1 face row) = 64 refs
 constexpr int STAGE_ROW = 28;    // 23 sums, v0, v1, v2, face, view
-constexpr int DEDUP_SLOTS = 128;
+#ifndef DMR_VTAB
+#define DMR_VTAB 256
+#endif
+#ifndef DMR_FTAB
+#define DMR_FTAB 256
+#endif
+#ifndef DMR_HITS_PER_BLOCK
+#define DMR_HITS_PER_BLOCK 1024
+#endif
+constexpr int VTAB = DMR_VTAB;   // vertex-row slots per workgroup (power of two)
+constexpr int FTAB = DMR_FTAB;   // face-row slots per workgroup (power of two)
+constexpr int TAB_PROBES = 16;
+constexpr uint32_t TAB_EMPTY = 0xffffffffu;
 
+// Workgroup-level aggregation of the gradient rows (LDS, 27 KB).
+// Global float atomics execute at the memory side at ~20 G 64-byte requests/s chip-wide whatever they carry
+// (MI355X_MICROARCH.md, "Global float atomics"): with one request per (segment, row) -- 3 vertex rows + 1 face row
+// per list entry -- this kernel was bound by exactly that (0.195 ms with the atomics, 0.110 ms without, 0.195 ms
+// with one dword per row).  A workgroup walks a contiguous range of records, i.e. neighbouring entries of a few
+// tile lists, and those are neighbouring faces of the same surfaces: their vertex rows repeat (0.8 distinct rows
+// per entry over such a range, not 3).  So segment totals are first added into LDS tables keyed by row -- insertion
+// with ds_cmpst, sums with ds_add_f64 -- and a row goes to HBM once per workgroup.  The cells are DOUBLES for the
+// atomic's rate, not for precision: ds_add_f32 retires one lane per ~3 cycles per CU, ds_add_f64 ten times that
+// (scripts/micro/lds_atomics.hip); an earlier version elected a leader per row with plain LDS stores and had
+// followers ds_add_f32 onto it inside a 16-segment window (0.182 ms).  A full table or a long probe sequence
+// falls back to the direct atomics for that row.
 struct HitsLds {
     float stage[4][STAGE_SEGS][STAGE_ROW];
-    int owner[4][DEDUP_SLOTS];
-    int list[4][64];
+    uint32_t vkey[VTAB]; uint32_t fkey[FTAB];
+    double vval[VTAB][7];   // dx dy dz dr dg db ddepth of row (view, vertex)
+    double fval[FTAB][2];   // dopacity dintense of row (view, face)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -622,71 +647,45 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Flush of the n <= 16 staged segment totals of one wave.  Global float atomics execute at the memory side at
-// ~20 G 64-byte requests/s chip-wide whatever they carry (MI355X_MICROARCH.md, "Global float atomics"): with one
-// request per (segment, row) -- 3 vertex rows + 1 face row -- this kernel was bound by exactly that (0.195 ms with
-// the atomics, 0.110 ms without, 0.195 ms with one dword per row).  Consecutive list entries of a tile are
-// neighbouring faces of one surface (the list is depth sorted), so their vertex rows repeat: every (segment, row)
-// reference finds the first reference to the same row in the window through a small wave-private hash (plain LDS
-// store + read-back elects a slot's owner, linear probing on a foreign owner), followers add their values onto the
-// leader's staged row (ds_add_f32, a few lanes), and only leaders go out -- 8 lanes per row, 8 rows per instruction.
-__device__ __forceinline__ void flush_staged(const TriParams& p, HitsLds& L, int wave, int lane, int n,
-                                             float* __restrict__ vrow, float* __restrict__ frow) {
+template <int SLOTS>
+__device__ __forceinline__ int tab_find(uint32_t* __restrict__ key, uint32_t rid) {
+    uint32_t slot = (rid * 2654435761u) & (uint32_t)(SLOTS - 1);
+    for (int i = 0; i < TAB_PROBES; i++) {
+        const uint32_t prev = atomicCAS(&key[slot], TAB_EMPTY, rid);
+        if (prev == TAB_EMPTY || prev == rid) return (int)slot;
+        slot = (slot + 1u) & (uint32_t)(SLOTS - 1);
+    }
+    return -1;
+}
+
+// The n <= 16 segment totals a wave has just staged: lane (seg, w) adds row w of segment seg (w < 3: a vertex
+// row, w == 3: the face row) into the workgroup's tables.
+__device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L, int wave, int lane, int n,
+                                                  float* __restrict__ vrow, float* __restrict__ frow) {
     wave_lds_sync();  // the staged rows are visible to the whole wave
     const int sg = lane >> 2, w = lane & 3;
-    const bool active = sg < n;
-    float* row = L.stage[wave][active ? sg : 0];
-    const int sb = __float_as_int(row[27]);
-    // row id: vertex rows first, face rows behind them (B * P and B * F are < 2^31 each)
-    const uint32_t rid = w < 3 ? (uint32_t)sb * (uint32_t)p.P + (uint32_t)__float_as_int(row[23 + w])
-                               : (uint32_t)p.B * (uint32_t)p.P + (uint32_t)sb * (uint32_t)p.F + (uint32_t)__float_as_int(row[26]);
-    volatile int* owner = L.owner[wave];
-    uint32_t slot = (rid * 2654435761u) >> 25;  // 128 slots
-    int leader = lane;
-    bool pending = active;
-    while (__ballot(pending)) {
-        if (pending) owner[slot] = lane;
-        wave_lds_sync();
-        const int wl = pending ? owner[slot] : lane;
-        const uint32_t rw = (uint32_t)__shfl((int)rid, wl, 64);
-        if (pending) {
-            if (rw == rid) { leader = wl; pending = false; }
-            else slot = (slot + 1u) & (uint32_t)(DEDUP_SLOTS - 1);
-        }
-        wave_lds_sync();
-    }
-    if (active && leader != lane) {  // follower: fold into the leader's staged row
-        float* tgt = L.stage[wave][leader >> 2];
-        const int lw = leader & 3;
+    if (sg < n) {
+        const float* row = L.stage[wave][sg];
+        const int sb = __float_as_int(row[27]);
         if (w < 3) {
+            const uint32_t rid = (uint32_t)sb * (uint32_t)p.P + (uint32_t)__float_as_int(row[23 + w]);
+            const int slot = tab_find<VTAB>(L.vkey, rid);
+            float v[7];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                atomicAdd(&tgt[3 * lw + c], row[3 * w + c]);
-                atomicAdd(&tgt[9 + 3 * lw + c], row[9 + 3 * w + c]);
+            for (int c = 0; c < 3; c++) { v[c] = row[3 * w + c]; v[3 + c] = row[9 + 3 * w + c]; }
+            v[6] = row[18 + w];
+            if (slot >= 0) {
+#pragma unroll
+                for (int c = 0; c < 7; c++) atomicAdd(&L.vval[slot][c], (double)v[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 7; c++) atomicAdd(&vrow[(int64_t)rid * VROW + c], v[c]);
             }
-            atomicAdd(&tgt[18 + lw], row[18 + w]);
         } else {
-            atomicAdd(&tgt[21], row[21]);
-            atomicAdd(&tgt[22], row[22]);
-        }
-    }
-    const uint64_t lmask = __ballot(active && leader == lane);
-    const int nrows = __popcll(lmask);
-    if (active && leader == lane) L.list[wave][__popcll(lmask & ((1ull << lane) - 1ull))] = lane;
-    wave_lds_sync();
-    const int grp = lane >> 3, comp = lane & 7;
-    for (int i0 = 0; i0 < nrows; i0 += 8) {
-        const int idx = i0 + grp;
-        if (idx >= nrows || (p.dbg & 512)) continue;
-        const int src = L.list[wave][idx];
-        const float* st = L.stage[wave][src >> 2];
-        const int sw = src & 3, vb = __float_as_int(st[27]);
-        if (sw < 3) {
-            if (comp == 7) continue;
-            const int ai = comp < 3 ? sw * 3 + comp : (comp < 6 ? 9 + sw * 3 + (comp - 3) : 18 + sw);
-            atomicAdd(&vrow[((int64_t)vb * p.P + __float_as_int(st[23 + sw])) * VROW + comp], st[ai]);
-        } else if (comp < 2) {
-            atomicAdd(&frow[((int64_t)vb * p.F + __float_as_int(st[26])) * FROW + comp], st[21 + comp]);
+            const uint32_t rid = (uint32_t)sb * (uint32_t)p.F + (uint32_t)__float_as_int(row[26]);
+            const int slot = tab_find<FTAB>(L.fkey, rid);
+            if (slot >= 0) { atomicAdd(&L.fval[slot][0], (double)row[21]); atomicAdd(&L.fval[slot][1], (double)row[22]); }
+            else { atomicAdd(&frow[(int64_t)rid * FROW], row[21]); atomicAdd(&frow[(int64_t)rid * FROW + 1], row[22]); }
         }
     }
     wave_lds_sync();  // the stage area may be refilled
@@ -704,12 +703,18 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     __shared__ HitsLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t HW = (int64_t)p.H * p.W;
-    // every wave owns a contiguous range of hit records, so that the dedup window of flush_staged sees
-    // neighbouring list entries
+    for (int i = tid; i < VTAB; i += 256) {
+        L.vkey[i] = TAB_EMPTY;
+#pragma unroll
+        for (int c = 0; c < 7; c++) L.vval[i][c] = 0.0;
+    }
+    for (int i = tid; i < FTAB; i += 256) { L.fkey[i] = TAB_EMPTY; L.fval[i][0] = 0.0; L.fval[i][1] = 0.0; }
+    __syncthreads();
+    // the workgroup owns a contiguous range of hit records (its waves consecutive quarters of it), so that the
+    // tables see neighbouring list entries
     const uint32_t nwaves = gridDim.x * 4u, niter = (nhits - first + 63u) / 64u;
     const uint32_t per_wave = (niter + nwaves - 1u) / nwaves;
     const uint32_t it0 = min(niter, (blockIdx.x * 4u + (uint32_t)wave) * per_wave), it1 = min(niter, it0 + per_wave);
-    int staged = 0;
     for (uint32_t it = it0; it < it1; it++) {
         const uint32_t base = first + it * 64u;
         const uint32_t hi_idx = base + lane;
@@ -819,26 +824,35 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         seg_scan_level<DPP_ROW_BCAST15, 0xA>(k, g);
         seg_scan_level<DPP_ROW_BCAST31, 0xC>(k, g);
 
-        // segment tails hold the totals: append them to the wave's stage area, flush whenever it is full
+        // segment tails hold the totals: stage them (wave-private LDS), 16 at a time, and add them into the tables
         const int kn = __shfl_down(k, 1, 64);
         const bool tail = valid && (lane == 63 || kn != k);
         const uint64_t tmask = __ballot(tail);
         const int ntail = __popcll(tmask);
         const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-        for (int t0 = 0; t0 < ntail;) {
-            const int take = min(STAGE_SEGS - staged, ntail - t0);
-            if (tail && rank >= t0 && rank < t0 + take) {
-                float* st = L.stage[wave][staged + rank - t0];
+        for (int t0 = 0; t0 < ntail; t0 += STAGE_SEGS) {
+            if (tail && rank >= t0 && rank < t0 + STAGE_SEGS) {
+                float* st = L.stage[wave][rank - t0];
 #pragma unroll
                 for (int c = 0; c < NACC; c++) st[c] = g[c];
                 st[23] = __int_as_float(v0); st[24] = __int_as_float(v1); st[25] = __int_as_float(v2);
                 st[26] = __int_as_float(face); st[27] = __int_as_float(b);
             }
-            staged += take; t0 += take;
-            if (staged == STAGE_SEGS) { flush_staged(p, L, wave, lane, staged, vrow, frow); staged = 0; }
+            accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
         }
     }
-    if (staged) flush_staged(p, L, wave, lane, staged, vrow, frow);
+    // every row of the tables goes out once: 8 lanes per vertex row (7 used), 2 lanes per face row
+    __syncthreads();
+    for (int s0 = 0; s0 < VTAB; s0 += 32) {
+        const int slot = s0 + (tid >> 3), comp = tid & 7;
+        const uint32_t rid = L.vkey[slot];
+        if (rid != TAB_EMPTY && comp < 7) atomicAdd(&vrow[(int64_t)rid * VROW + comp], (float)L.vval[slot][comp]);
+    }
+    for (int s0 = 0; s0 < FTAB; s0 += 128) {
+        const int slot = s0 + (tid >> 1), comp = tid & 1;
+        const uint32_t rid = L.fkey[slot];
+        if (rid != TAB_EMPTY) atomicAdd(&frow[(int64_t)rid * FROW + comp], (float)L.fval[slot][comp]);
+    }
 }
 
 #pragma clang fp contract(off)
@@ -911,7 +925,7 @@ void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uin
     TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     TriParams p = make_params(s, 0, 0, 0, 0, vproj, nullptr, face_list, none);
     // grid from the host-known bound; >= 8 rounds of 64 records per wave
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + 2047u) / 2048u, 256u * 16u);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + DMR_HITS_PER_BLOCK - 1) / DMR_HITS_PER_BLOCK, 256u * 64u);
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
     k_tri_backward_hits<<<dim3(std::max(1u, blocks)), dim3(256), 0, st>>>(p, pixrec, hits, hit_total, capacity, vrow, frow);
 }
