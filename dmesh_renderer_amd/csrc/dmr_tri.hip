@@ -821,12 +821,13 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         seg_scan_level<DPP_ROW_SHR + 2, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 4, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 8, 0xF>(k, g);
-        seg_scan_level<DPP_ROW_BCAST15, 0xA>(k, g);
-        seg_scan_level<DPP_ROW_BCAST31, 0xC>(k, g);
+        // The scan stops at the 16-lane DPP rows: the tables below take partial sums just as well, so an entry that
+        // crosses a row boundary simply contributes one more partial (the two row-broadcast levels cost 46 VALU
+        // per round; the extra partials ride in lanes that were idle anyway).
 
         // segment tails hold the totals: stage them (wave-private LDS), 16 at a time, and add them into the tables
         const int kn = __shfl_down(k, 1, 64);
-        const bool tail = valid && (lane == 63 || kn != k);
+        const bool tail = valid && ((lane & 15) == 15 || kn != k);
         const uint64_t tmask = __ballot(tail);
         const int ntail = __popcll(tmask);
         const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
@@ -838,11 +839,12 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
                 st[23] = __int_as_float(v0); st[24] = __int_as_float(v1); st[25] = __int_as_float(v2);
                 st[26] = __int_as_float(face); st[27] = __int_as_float(b);
             }
-            accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
+            if (!(p.dbg & 512)) accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
         }
     }
     // every row of the tables goes out once: 8 lanes per vertex row (7 used), 2 lanes per face row
     __syncthreads();
+    if (p.dbg & 1024) return;
     for (int s0 = 0; s0 < VTAB; s0 += 32) {
         const int slot = s0 + (tid >> 3), comp = tid & 7;
         const uint32_t rid = L.vkey[slot];
