@@ -53,6 +53,7 @@ struct ImageState {
     uint32_t* tile_hits; uint32_t* hit_offset; unsigned long long* hit_total; uint32_t* tile_order;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
+    int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
 };
 struct BinningState { uint64_t* keys; uint32_t* face_list; };
 
@@ -73,6 +74,7 @@ size_t carve_face(void* b, size_t BF, size_t F, size_t T, bool tet, FaceState& s
 size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, ImageState& s) {
     Carver c(b);
     s.mats = c.take<float>(64 * B);
+    s.seed = c.take<int>(1);
     // counters, zeroed by ONE memset at the start of a forward: [tile_count | tile_hits]
     s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles);
     s.hit_offset = c.take<uint32_t>(ntiles + 1); s.hit_total = c.take<unsigned long long>(1);
@@ -122,8 +124,6 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     d.r1 = std::max(d.r0, std::min(d.gy, d.r1));
     d.ntiles = s->B * d.gx * d.gy;
     d.BP = (size_t)s->B * s->P; d.BF = (size_t)s->B * s->F; d.npix = (size_t)s->B * s->W * s->H;
-    if (tet && s->ray_random_seed > 0)
-        return fail("ray_random_seed > 0 (cuRAND XORWOW jitter, cuda_renderer/forward.cu:82-88) is not implemented: parity unpinned");
     if (tet && s->F > 0 && s->P > 0 && (!s->tets || !s->face_tets || !s->tet_faces)) return fail("tet topology missing");
     return 0;
 }
@@ -408,7 +408,7 @@ int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, floa
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
         dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
-                               is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec};
+                               is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec, is.seed};
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tet_prep(sc, img, st);
         dmr::launch_tet_first_intersect(sc, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
@@ -432,7 +432,7 @@ int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, true, is);
     carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, true, fs);
     dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
-                           is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec};
+                           is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec, is.seed};
     const dmr_scene sc = canonical(s, is.mats);
     dmr::launch_tet_backward(sc, d.gx, d.gy, d.r0, d.r1, img, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, st);
     DMR_HIP(hipGetLastError());

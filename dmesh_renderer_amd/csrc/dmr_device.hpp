@@ -81,11 +81,38 @@ __device__ __forceinline__ Rect tile_rect(V2 p0, V2 p1, V2 p2, int gx, int gy, i
 // Per-pixel world-space ray, tri generateRaysCUDA (cuda_rasterizer/forward.cu:184-231) and the
 // seed <= 0 branch of the tet one (cuda_renderer/forward.cu:90-145).  Recomputed inside the
 // compositing kernels instead of being stored (saves 24 B/pixel each way).
+// Seeded ray jitter of the tet renderer (cuda_renderer/forward.cu:82-88,120-123): the reference draws two
+// cuRAND XORWOW uniforms per pixel from a per-call cudaMalloc'ed state array, curand_init(seed, idx, 0).
+// XORWOW's skip-ahead tables are not reproducible here, so the bits are NOT the reference's (parity unpinned);
+// what is kept is the distribution and the mapping: u in (0, 1] -> pixel - 0.5 + 0.5 u (Q20).  The generator is
+// counter based (Philox-4x32-10, key = seed, counter = pixel index), so the three kernels that need a pixel's
+// ray recompute the same one without any state in memory.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t& o0, uint32_t& o1) {
+    uint32_t c2 = 0u, c3 = 0u, k1 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1;
+}
+// curand_uniform's mapping of 32 random bits to (0, 1]
+__device__ __forceinline__ float uniform_01(uint32_t x) { return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+
 template <bool TET>
 __device__ __forceinline__ void pixel_ray(const float* __restrict__ inv_mv, const float* __restrict__ inv_proj,
-                                          int px, int py, int W, int H, V3& o, V3& d) {
+                                          int px, int py, int W, int H, V3& o, V3& d, int seed = 0, uint64_t idx = 0) {
     o = {inv_mv[12], inv_mv[13], inv_mv[14]};
     V2 pixf = {px + 0.5f, py + 0.5f};
+    if (TET && seed > 0) {  // idx = (view * H + y) * W + x, the reference's thread rank
+        uint32_t r0, r1;
+        philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)seed, r0, r1);
+        pixf.x = (float)px - 0.5f + (0.5f * uniform_01(r0));
+        pixf.y = (float)py - 0.5f + (0.5f * uniform_01(r1));
+    }
     V2 nd = {pix2ndc(pixf.x, W), pix2ndc(pixf.y, H)};
     V4 pv = xform4x4({nd.x, nd.y, -1.0f}, inv_proj);
     V4 pw = xform4x4({pv.x, pv.y, pv.z}, inv_mv);

@@ -72,6 +72,7 @@ struct TetImageState {
     float* final_log_T; float* final_prev_log_T; uint32_t* n_contrib;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     void* facerec; void* colrec; void* tetrec;  // packed march records (dmr_tet.hip), in the face buffer
+    int* seed;                                  // ray_random_seed of the forward (image buffer)
 };
 size_t tet_facerec_bytes();
 size_t tet_colrec_bytes();

@@ -29,6 +29,7 @@ struct TetParams {
     const float* mv; const float* proj; const float* inv_mv; const float* inv_proj;
     const float* faces_intense; const float* bg;
     const int* tets; const int* face_tets; const int* tet_faces;
+    const int* seed;  // ray_random_seed of the forward, kept in the image buffer for the backward
     const TetFaceRec* facerec; const TetColRec* colrec; const int4* tetrec;
     TetImageState img;
 };
@@ -48,8 +49,10 @@ struct TetParams {
 __global__ void __launch_bounds__(256)
 k_tet_prep_faces(int F, const float* __restrict__ verts, const int* __restrict__ faces,
                  const float* __restrict__ verts_color, const float* __restrict__ faces_opacity,
-                 const int* __restrict__ face_tets, TetFaceRec* __restrict__ facerec, TetColRec* __restrict__ colrec) {
+                 const int* __restrict__ face_tets, TetFaceRec* __restrict__ facerec, TetColRec* __restrict__ colrec,
+                 int seed, int* __restrict__ seed_slot) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f == 0) *seed_slot = seed;
     if (f >= F) return;
     const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
     const V3 p0 = load_v3(verts, v0), p1 = load_v3(verts, v1), p2 = load_v3(verts, v2);
@@ -122,7 +125,7 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
     const int64_t bpix = (int64_t)b * p.H * p.W + (int64_t)p.W * py + px;
 
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
-    if (inside) pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
+    if (inside) pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
 
     const int tile = (b * p.gy + ty) * p.gx + tx;
     const uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
@@ -242,7 +245,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     if (px >= p.W || py >= p.H) return;
     const int64_t HW = (int64_t)p.H * p.W, pix_id = (int64_t)p.W * py + px, bpix = (int64_t)b * HW + pix_id;
     V3 ro, rd;
-    pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
+    pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
     const float* mv = p.mv + 16 * b;
     const float* pr = p.proj + 16 * b;
     const int first_face = p.img.first_face[bpix], first_tet = p.img.first_tet[bpix];
@@ -364,7 +367,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
         const float bd_dot = 0.f + (float)(1.0 * (double)dpd);
 
         V3 ro, rd;
-        pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
+        pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
         const float* mv = p.mv + 16 * b;
         const float* pr = p.proj + 16 * b;
 
@@ -460,6 +463,7 @@ static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImag
     p.mv = s.mv_mats; p.proj = s.proj_mats; p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats;
     p.faces_intense = s.faces_intense; p.bg = s.background;
     p.tets = s.tets; p.face_tets = s.face_tets; p.tet_faces = s.tet_faces;
+    p.seed = img.seed;
     p.facerec = reinterpret_cast<const TetFaceRec*>(img.facerec);
     p.colrec = reinterpret_cast<const TetColRec*>(img.colrec);
     p.tetrec = reinterpret_cast<const int4*>(img.tetrec);
@@ -471,10 +475,9 @@ size_t tet_facerec_bytes() { return sizeof(TetFaceRec); }
 size_t tet_colrec_bytes() { return sizeof(TetColRec); }
 
 void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st) {
-    if (s.F > 0)
-        k_tet_prep_faces<<<dim3((unsigned)((s.F + 255) / 256)), dim3(256), 0, st>>>(
-            s.F, s.verts, s.faces, s.verts_color, s.faces_opacity, s.face_tets,
-            reinterpret_cast<TetFaceRec*>(img.facerec), reinterpret_cast<TetColRec*>(img.colrec));
+    k_tet_prep_faces<<<dim3((unsigned)std::max(1, (s.F + 255) / 256)), dim3(256), 0, st>>>(
+        s.F, s.verts, s.faces, s.verts_color, s.faces_opacity, s.face_tets,
+        reinterpret_cast<TetFaceRec*>(img.facerec), reinterpret_cast<TetColRec*>(img.colrec), s.ray_random_seed, img.seed);
     if (s.T > 0)
         k_tet_prep_tets<<<dim3((unsigned)((s.T + 255) / 256)), dim3(256), 0, st>>>(
             s.T, s.F, s.verts, s.tets, s.tet_faces, reinterpret_cast<const TetFaceRec*>(img.facerec),

@@ -63,7 +63,9 @@ typedef struct dmr_scene {
     const int32_t* tets;         /* [T,4]  tet renderer only */
     const int32_t* face_tets;    /* [F,2]  tet renderer only, -1 = no tet */
     const int32_t* tet_faces;    /* [T,4]  tet renderer only */
-    int32_t ray_random_seed;     /* tet renderer only; <= 0: rays through pixel centres */
+    int32_t ray_random_seed;     /* tet renderer only; <= 0: rays through pixel centres; > 0: jittered rays, pixel - 0.5 + 0.5 u
+                                  * (cuda_renderer/forward.cu:120-123) with u from Philox-4x32-10(key = seed, counter = pixel):
+                                  * same distribution as the reference, not its cuRAND XORWOW bits (parity unpinned) */
     /* Tile-row band [row_begin, row_end) this call renders (multi-GPU shard by tile
      * rows); 0,0 means all rows.  Pixels outside the band are left untouched. */
     int32_t row_begin, row_end;

@@ -254,7 +254,6 @@ namespace {
 bool check_scene(const dmro_scene* s, bool tet) {
     if (!s) { g_err = "null scene"; return false; }
     if (s->B <= 0 || s->W <= 0 || s->H <= 0 || s->P < 0 || s->F < 0) { g_err = "bad dimensions"; return false; }
-    if (tet && s->ray_random_seed > 0) { g_err = "ray_random_seed > 0: cuRAND jitter is parity-unpinned, not restated"; return false; }
     return true;
 }
 
@@ -393,7 +392,24 @@ void bin_and_sort(const dmro_scene* s, dmro_state* st) {
     }
 }
 
-// generateRaysCUDA: tri forward.cu:184-231; tet cuda_renderer/forward.cu:90-145 (seed <= 0 branch)
+// Seeded jitter, cuda_renderer/forward.cu:82-88,120-123: pixf = pixel - 0.5 + 0.5 * curand_uniform(state[idx]),
+// two draws per pixel.  PARITY UNPINNED: cuRAND's XORWOW sequence (curand_init(seed, idx, 0)) cannot be restated
+// here (its skip-ahead tables are not in the reference tree); the draws come from Philox-4x32-10 with key = seed
+// and counter = pixel index, mapped to (0, 1] exactly as curand_uniform maps 32 bits.
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t& o0, uint32_t& o1) {
+    uint32_t c2 = 0u, c3 = 0u, k1 = 0u;
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1;
+}
+static float uniform_01(uint32_t x) { return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+
+// generateRaysCUDA: tri forward.cu:184-231; tet cuda_renderer/forward.cu:90-145
 void generate_rays(const dmro_scene* s, dmro_state* st) {
     const int B = s->B, W = s->W, H = s->H;
     const size_t N = (size_t)B * W * H;
@@ -408,6 +424,12 @@ void generate_rays(const dmro_scene* s, dmro_state* st) {
         f3 o = {imv[12], imv[13], imv[14]};
         int pixel_x = pixel_id % W, pixel_y = pixel_id / W;
         f2 pixf = {pixel_x + 0.5f, pixel_y + 0.5f};
+        if (st->tet && s->ray_random_seed > 0) {
+            uint32_t r0, r1;
+            philox4x32_10((uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)s->ray_random_seed, r0, r1);
+            pixf.x = (float)pixel_x - 0.5f + (0.5f * uniform_01(r0));
+            pixf.y = (float)pixel_y - 0.5f + (0.5f * uniform_01(r1));
+        }
         f2 pix_ndc = {pix2Ndc(pixf.x, W), pix2Ndc(pixf.y, H)};
         f4 pix_view = transformPoint4x4({pix_ndc.x, pix_ndc.y, -1.0f}, ipr);
         f4 pix_world = transformPoint4x4({pix_view.x, pix_view.y, pix_view.z}, imv);

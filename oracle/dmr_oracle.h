@@ -42,7 +42,7 @@ typedef struct dmro_scene {
     const int32_t* tets;         /* [T,4]  (tet only) */
     const int32_t* face_tets;    /* [F,2]  (tet only, -1 = none) */
     const int32_t* tet_faces;    /* [T,4]  (tet only) */
-    int ray_random_seed;         /* tet only; > 0 is rejected (parity unpinned) */
+    int ray_random_seed;         /* tet only; > 0: Philox ray jitter (parity unpinned vs cuRAND) */
     /* tile-row band [row_begin,row_end) rendered by this call; 0,0 = all rows.
      * Not a reference feature: mirrors the multi-GPU shard of the product. */
     int row_begin, row_end;

@@ -323,8 +323,24 @@ def test_tet_topology_of_scene():
             assert set(d["faces"][f].tolist()) <= set(d["tets"][t].tolist())
 
 
-def test_tet_seed_rejected(oracle):
-    d = scenes.kuhn_tets(2, 1, 32, 32)
-    sc = oracle.scene_from_module_inputs(d, 32, 32, seed=3)
-    with pytest.raises(RuntimeError, match="parity-unpinned"):
-        oracle.tet_forward(sc)
+def test_tet_seeded_jitter_properties(oracle):
+    """ray_random_seed > 0: the oracle's restatement of cuda_renderer/forward.cu:120-123 with a Philox stream
+    (parity with cuRAND unpinned).  The jittered pixel position lies in (x - 0.5, x] x (y - 0.5, y]: with an
+    identity-like camera the ray direction must fall between the rays through those corners; the same seed repeats,
+    another seed differs, seed 0 goes through the pixel centres."""
+    H = W = 32
+    d = scenes.kuhn_tets(2, 1, H, W, seed=0)
+    rays = {}
+    for seed in (0, 5, 5, 6):
+        sc = oracle.scene_from_module_inputs(d, H, W, seed=seed)
+        _, _, _, st = oracle.tet_forward(sc)
+        rays.setdefault(seed, []).append(st.get("ray_d").reshape(H, W, 3).copy())
+    assert np.array_equal(rays[5][0], rays[5][1])
+    assert not np.array_equal(rays[5][0], rays[6][0]) and not np.array_equal(rays[5][0], rays[0][0])
+    # direction of pixel (x, y) with seed 0 is the ray through (x + 0.5, y + 0.5); jittered rays through
+    # (x - 0.5, x]: between the centre rays of pixel x - 1 and pixel x, i.e. angularly within one pixel of both
+    c = rays[0][0]
+    j = rays[5][0]
+    step = np.linalg.norm(c[:, 1:] - c[:, :-1], axis=-1).max()
+    assert np.linalg.norm(j[:, 1:] - c[:, 1:], axis=-1).max() <= 1.5 * step
+    assert np.linalg.norm(j - c, axis=-1).min() > 0.0

@@ -100,9 +100,26 @@ def test_module_autograd(oracle, hip_device):
     assert rel_err(fo.grad.cpu().numpy(), og["faces_opacity"]) <= GRAD_TOL
 
 
-def test_seeded_jitter_rejected(hip_device):
+def test_seeded_jitter(oracle, hip_device):
+    """ray_random_seed > 0 (cuda_renderer/forward.cu:82-88,120-123).  Parity with cuRAND is UNPINNED: library and
+    oracle draw from the same Philox-4x32-10 stream (key = seed, counter = pixel index), so they are compared with
+    each other; the seed must change the image, and the backward must re-derive the forward's jittered rays."""
     from dmesh_renderer_amd import _C
-    d, B, H, W = _scene("small")
+    d, B, H, W = _scene("two_views_ragged")
     args = c_args(d, hip_device, tet=True)
-    with pytest.raises(RuntimeError, match="ray_random_seed"):
-        _C.render_tets(*args, H, W, 7)
+    gc, gd = upstream_grads(B, H, W)
+    imgs = {}
+    for seed in (0, 7, 8):
+        sc = oracle.scene_from_module_inputs(d, H, W, seed=seed)
+        ocolor, odepth, oactive, ost = oracle.tet_forward(sc)
+        out = _C.render_tets(*args, H, W, seed)
+        th.cuda.synchronize()
+        np.testing.assert_array_equal(out[2].cpu().numpy(), oactive)
+        assert np.abs(out[0].cpu().numpy() - ocolor).max() <= FWD_TOL
+        assert np.abs(out[1].cpu().numpy() - odepth).max() <= FWD_TOL
+        og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+        g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *out[3:7])
+        for got, key in zip(g, ("verts_color", "faces_opacity")):
+            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (seed, key)
+        imgs[seed] = out[0].cpu().numpy()
+    assert np.abs(imgs[7] - imgs[0]).max() > 1e-3 and np.abs(imgs[7] - imgs[8]).max() > 1e-3
