@@ -267,6 +267,35 @@ def render_tets_backward(background, verts, faces, verts_color, faces_opacity, m
     return g_vcolor, g_fop
 
 
+def invert_mats(*mats: th.Tensor):
+    """th.inverse of [B,4,4] float32 HIP tensors with ONE library kernel for all of them (dmr_invert_mats: adjugate in
+    double precision).  Extension over the reference's `_C` (its wrapper calls th.inverse twice per forward,
+    dmesh_renderer/__init__.py:62-63: two batched LU factorisations, ~0.12 ms of small kernels on the GPU).
+    Returns contiguous tensors."""
+    lib = _lib.load()
+    dev = _device_of(mats[0])
+    prepared = []
+    for m in mats:
+        if m.dim() != 3 or m.size(1) != 4 or m.size(2) != 4:
+            _err("matrices must have dimensions (B, 4, 4)")
+        prepared.append(_mat(m, "matrix"))
+    out = th.empty((sum(m.size(0) for m in mats), 4, 4), dtype=th.float32, device=dev)
+    with th.cuda.device(dev):
+        stream = C.c_void_p(th.cuda.current_stream(dev).cuda_stream)
+        off = 0
+        # consecutive matrices of one layout could share a launch; two launches of one tiny kernel are cheap enough
+        for (t, flag) in prepared:
+            n = t.size(0)
+            if n and lib.dmr_invert_mats(t.data_ptr(), n, flag, out[off:].data_ptr(), stream):
+                _raise_lib()
+            off += n
+    res, off = [], 0
+    for m in mats:
+        res.append(out[off:off + m.size(0)])
+        off += m.size(0)
+    return tuple(res)
+
+
 def export(name: str, call_args: Tuple, is_tet: bool, num_rendered: int, buffers, H: int, W: int,
            dtype=th.float32) -> th.Tensor:
     """Parity/debug helper: copy one forward intermediate out of the scratch buffers

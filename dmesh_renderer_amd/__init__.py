@@ -35,6 +35,12 @@ class TetRenderSettings(NamedTuple):
 
 
 def _with_inverses(mv_mats: th.Tensor, proj_mats: th.Tensor) -> Tuple[th.Tensor, ...]:
+    """(mv, proj, mv^-1, proj^-1), reference :62-63.  On a HIP device the two inverses come from one library kernel
+    (_C.invert_mats) instead of two th.inverse calls; anything else (CPU tensors in the wrapper tests, other
+    dtypes) takes th.inverse like the reference."""
+    if mv_mats.is_cuda and proj_mats.is_cuda and mv_mats.dtype == th.float32 and proj_mats.dtype == th.float32 \
+            and mv_mats.dim() == 3 and proj_mats.dim() == 3:
+        return (mv_mats, proj_mats) + _C.invert_mats(mv_mats, proj_mats)
     return mv_mats, proj_mats, th.inverse(mv_mats), th.inverse(proj_mats)
 
 

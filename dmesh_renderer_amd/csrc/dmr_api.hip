@@ -439,6 +439,44 @@ int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     return 0;
 }
 
+// ---- 4x4 inverses (caller-side step) ---------------------------------------
+namespace {
+__global__ void k_invert_mats(const float* __restrict__ in, int count, int transposed, float* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= count) return;
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = (double)in[16 * m + (transposed ? 4 * (k & 3) + (k >> 2) : k)];  // a[4*i + j]
+    // cofactor expansion with the six 2x2 minors of the upper and of the lower two rows
+    const double s0 = a[0] * a[5] - a[1] * a[4], s1 = a[0] * a[6] - a[2] * a[4], s2 = a[0] * a[7] - a[3] * a[4];
+    const double s3 = a[1] * a[6] - a[2] * a[5], s4 = a[1] * a[7] - a[3] * a[5], s5 = a[2] * a[7] - a[3] * a[6];
+    const double c5 = a[10] * a[15] - a[11] * a[14], c4 = a[9] * a[15] - a[11] * a[13], c3 = a[9] * a[14] - a[10] * a[13];
+    const double c2 = a[8] * a[15] - a[11] * a[12], c1 = a[8] * a[14] - a[10] * a[12], c0 = a[8] * a[13] - a[9] * a[12];
+    const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const double r = 1.0 / det;
+    double b[16];
+    b[0] = (a[5] * c5 - a[6] * c4 + a[7] * c3) * r;   b[1] = (-a[1] * c5 + a[2] * c4 - a[3] * c3) * r;
+    b[2] = (a[13] * s5 - a[14] * s4 + a[15] * s3) * r; b[3] = (-a[9] * s5 + a[10] * s4 - a[11] * s3) * r;
+    b[4] = (-a[4] * c5 + a[6] * c2 - a[7] * c1) * r;  b[5] = (a[0] * c5 - a[2] * c2 + a[3] * c1) * r;
+    b[6] = (-a[12] * s5 + a[14] * s2 - a[15] * s1) * r; b[7] = (a[8] * s5 - a[10] * s2 + a[11] * s1) * r;
+    b[8] = (a[4] * c4 - a[5] * c2 + a[7] * c0) * r;   b[9] = (-a[0] * c4 + a[1] * c2 - a[3] * c0) * r;
+    b[10] = (a[12] * s4 - a[13] * s2 + a[15] * s0) * r; b[11] = (-a[8] * s4 + a[9] * s2 - a[11] * s0) * r;
+    b[12] = (-a[4] * c3 + a[5] * c1 - a[6] * c0) * r; b[13] = (a[0] * c3 - a[1] * c1 + a[2] * c0) * r;
+    b[14] = (-a[12] * s3 + a[13] * s1 - a[14] * s0) * r; b[15] = (a[8] * s3 - a[9] * s1 + a[10] * s0) * r;
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[16 * m + k] = (float)b[k];
+}
+}  // namespace
+
+int dmr_invert_mats(const float* in, int count, int transposed, float* out, void* stream) {
+    if (count < 0 || (count > 0 && (!in || !out))) return fail("dmr_invert_mats: bad arguments");
+    if (count == 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    k_invert_mats<<<dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st>>>(in, count, transposed, out);
+    DMR_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- parity/debug export ---------------------------------------------------------------------
 namespace {
 __global__ void k_export_vproj(const float4* v, int64_t n, int what, float* dst) {

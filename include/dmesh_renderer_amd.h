@@ -104,6 +104,14 @@ int dmr_tet_backward(const dmr_scene* scene, const float* dL_dcolor, const float
                      float* dL_dvcolor, float* dL_dfopacity,
                      dmr_alloc_fn alloc, void* alloc_ctx, void* stream);
 
+/* Caller-side step of the path: the reference wrapper computes th.inverse of the (transposed) model-view and
+ * projection matrices on every forward (dmesh_renderer/__init__.py:62-63,298-299) -- on a GPU that is two batched
+ * LU factorisations, ~0.12 ms of small kernels.  This inverts `count` 4x4 matrices with one kernel (adjugate /
+ * determinant in double precision, rounded to fp32 once): out[16*m + 4*i + j] = inverse(A_m)[i][j] with
+ * A_m[i][j] = in[16*m + 4*i + j], or in[16*m + i + 4*j] when `transposed` (the storage behind a .transpose(1, 2)
+ * view).  A singular matrix gives inf/nan entries, as a division by a zero determinant does. */
+int dmr_invert_mats(const float* in, int count, int transposed, float* out, void* stream);
+
 /* Parity/debug export of forward intermediates held in the scratch buffers.
  * name: "image" (f32 [B*P,2]) "ndc_z" (f32 [B*P]) "key_depth" (f32 [B*F]) "max_depth" (tet, f32 [B*F])
  * "tiles_touched" (u32 [B*F]) "ranges" (u32 [B*Nt,2]) "face_list" (u32 [R]) "final_T" "final_prev_T"

@@ -157,3 +157,21 @@ def test_c3_tet_matches_oracle_and_repeats(hip_device, oracle):
     for got, twice, k in zip(g, g2, ("verts_color", "faces_opacity")):
         assert rel_err(got.cpu().numpy(), og[k]) <= GRAD_TOL, k
         assert rel_err(twice.cpu().numpy(), 2.0 * got.cpu().numpy()) <= 1e-5, k
+
+
+def test_invert_mats_matches_float64_inverse(hip_device):
+    """dmr_invert_mats (the wrapper's th.inverse replacement on a HIP device): contiguous and transposed-view
+    inputs, several matrices per call, against numpy's float64 inverse."""
+    from dmesh_renderer_amd import _C
+    d = scenes.layered_sheets(2, 5, 3, 64, 64, seed=2)
+    mv, proj = d["mv_mats"].to(hip_device), d["proj_mats"].to(hip_device)
+    for a, b in ((mv.transpose(1, 2), proj.transpose(1, 2)), (mv.contiguous(), proj.transpose(1, 2)),
+                 (mv.transpose(1, 2).contiguous(), proj.contiguous())):
+        ia, ib = _C.invert_mats(a, b)
+        assert ia.is_contiguous() and ib.is_contiguous() and ia.shape == a.shape
+        for got, src in ((ia, a), (ib, b)):
+            ref = np.linalg.inv(src.cpu().numpy().astype(np.float64))
+            assert np.abs(got.cpu().numpy() - ref).max() <= 4e-7 * max(1.0, np.abs(ref).max())
+            # and no worse than th.inverse in float32 on the same device
+            t = th.inverse(src).cpu().numpy()
+            assert np.abs(got.cpu().numpy() - ref).max() <= np.abs(t - ref).max() + 1e-7 * np.abs(ref).max()
