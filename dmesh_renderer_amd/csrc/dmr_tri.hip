@@ -749,7 +749,8 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
                 const V3 xT = view_o - xp0, xE1 = xp1 - xp0, xE2 = xp2 - xp0;
                 const V3 xQ = dmr::cross(xT, xE1), xP = dmr::cross(xd, xE2);
                 denom = dmr::dot(xP, xE1);
-                const float inv_denom = fast_rcp(denom);
+                const float inv_denom = 1.0f / denom;  // IEEE like the forward: a 1-ulp v_rcp_f32 flips the region of a
+                                                       // (u, v) on a border now and then (4 vertices at C5's 376 M pairs)
                 nu = dmr::dot(xP, xT);
                 iu = nu * inv_denom;
                 iv = dmr::dot(xQ, xd) * inv_denom;
@@ -776,16 +777,27 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             const float dL_diu = e1 * duc_du + e2 * dvc_du;
             const float dL_div = e1 * duc_dv + e2 * dvc_dv;
             // ray_tri_intersection_grad (auxiliary.h:288-333; Q11: the "v" numerator is t's, Q12: no clamp of
-            // denom^2), regrouped: with a = dL_diu / denom^2, b = dL_div / denom^2, w0 = P.T, w1 = denom, w2 = Q.E2
-            //   dL/dE1 = s3 P + s2 (E2 x T),  dL/dE2 = s1 (T x d) + s3 (E1 x d) + s2 Q,  dL/dT = s1 P + s2 (E1 x E2)
-            //   s1 = a w1, s2 = b w1, s3 = -(a w0 + b w2);  p1 <- dL/dE1, p2 <- dL/dE2, p0 <- -(dL/dE1 + dL/dE2 + dL/dT)
-            const float dinv = fast_rcp(denom * denom);
-            const float ga = dL_diu * dinv, gb = dL_div * dinv;
-            const float s1 = ga * denom, s2 = gb * denom, s3 = -(ga * nu + gb * dot(Q, E2));
-            const F3 dp1 = s3 * Pv + s2 * cross(E2, Tv);
-            const F3 dp2 = s1 * cross(Tv, d) + s3 * cross(E1, d) + s2 * Q;
-            const F3 dT = s1 * Pv + s2 * cross(E1, E2);
-            const F3 dp0 = -(dp1 + dp2 + dT);
+            // denom^2) in the reference's own order of operations and without contraction (the V3 helpers): for a
+            // grazing ray 1 / denom^2 is huge and the six derivative vectors are differences of nearly equal terms,
+            // so this part stays bit-comparable with the oracle.  (A regrouped form with three scalars per hit saves
+            // ~30 instructions; the kernel is not bound by them.)
+            const float dinv = 1.0f / (denom * denom);
+            V3 dp0, dp1, dp2;
+            {
+                const V3 xP = {Pv.x, Pv.y, Pv.z}, xT = {Tv.x, Tv.y, Tv.z}, xE1 = {E1.x, E1.y, E1.z}, xE2 = {E2.x, E2.y, E2.z};
+                const V3 xQ = {Q.x, Q.y, Q.z}, xd = {d.x, d.y, d.z};
+                const float w0 = nu, w1 = denom, w2 = dmr::dot(xQ, xE2);
+                const V3 du_dE1 = (-1.0f * xP * w0) * dinv;
+                const V3 du_dE2 = (dmr::cross(xT, xd) * w1 - w0 * dmr::cross(xE1, xd)) * dinv;
+                const V3 du_dT = (xP * w1) * dinv;
+                const V3 dv_dE1 = ((dmr::cross(xE2, xT) * w1) - (w2 * xP)) * dinv;
+                const V3 dv_dE2 = ((xQ * w1) - (w2 * dmr::cross(xE1, xd))) * dinv;
+                const V3 dv_dT = dmr::cross(xE1, xE2) * w1 * dinv;
+                const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
+                dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
+                dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
+                dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
+            }
 
             g[0] = dp0.x; g[1] = dp0.y; g[2] = dp0.z;
             g[3] = dp1.x; g[4] = dp1.y; g[5] = dp1.z;
@@ -927,7 +939,9 @@ void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uin
     TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     TriParams p = make_params(s, 0, 0, 0, 0, vproj, nullptr, face_list, none);
     // grid from the host-known bound; >= 8 rounds of 64 records per wave
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + DMR_HITS_PER_BLOCK - 1) / DMR_HITS_PER_BLOCK, 256u * 64u);
+    // one workgroup per DMR_HITS_PER_BLOCK records: the LDS tables are sized for that range (a longer one overflows
+    // them into the direct-atomic fallback: 14.7 ms instead of ~4 at C5 when the grid was capped)
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + DMR_HITS_PER_BLOCK - 1) / DMR_HITS_PER_BLOCK, 0x7fffffffu);
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
     k_tri_backward_hits<<<dim3(std::max(1u, blocks)), dim3(256), 0, st>>>(p, pixrec, hits, hit_total, capacity, vrow, frow);
 }
