@@ -177,8 +177,8 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     int* host_R = reinterpret_cast<int*>(sr->slot);
 
     auto front = [&]() -> int {
-        DMR_HIP(hipMemsetAsync(is.tile_count, 0, (size_t)(reinterpret_cast<char*>(is.tile_hits + d.ntiles) - reinterpret_cast<char*>(is.tile_count)), st));
-        dmr::launch_project_verts(*s, ps.vproj, is.mats, st);
+        // (tile_count | tile_hits are contiguous: zeroed by k_project_verts, a slice per block)
+        dmr::launch_project_verts(*s, ps.vproj, is.mats, is.tile_count, (size_t)(is.tile_hits + d.ntiles - is.tile_count), st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
         dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, is.tile_order, st);

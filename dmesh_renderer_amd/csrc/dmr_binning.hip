@@ -36,7 +36,13 @@ __global__ void __launch_bounds__(256)
 k_project_verts(int B, int P, const float* __restrict__ verts, const float* __restrict__ mv_mats,
                 const float* __restrict__ proj_mats, const float* __restrict__ inv_mv_mats,
                 const float* __restrict__ inv_proj_mats, int transposed, const float* __restrict__ verts_depth,
-                int W, int H, float4* __restrict__ vproj, float* __restrict__ mats) {
+                int W, int H, float4* __restrict__ vproj, float* __restrict__ mats,
+                uint32_t* __restrict__ counters, uint32_t ncounters) {
+    {   // every block zeroes a slice of the tile counters (tile_count | tile_hits) the next kernels add into
+        const uint32_t per = (ncounters + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = min(ncounters, blockIdx.x * per), z1 = min(ncounters, z0 + per);
+        for (uint32_t i = z0 + threadIdx.x; i < z1; i += 256) counters[i] = 0u;
+    }
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < 64 * B; i += 256) {
             const int m = i / (16 * B), r = i % (16 * B);
@@ -496,12 +502,13 @@ k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, const ui
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
-void launch_project_verts(const dmr_scene& s, float4* vproj, float* mats, hipStream_t st) {
+void launch_project_verts(const dmr_scene& s, float4* vproj, float* mats, uint32_t* counters, size_t ncounters,
+                          hipStream_t st) {
     const int64_t n = (int64_t)s.B * s.P;
     StageScope t(DMR_STAGE_PROJECT, st);
     k_project_verts<<<dim3((unsigned)std::max<int64_t>(1, (n + 255) / 256)), dim3(256), 0, st>>>(
         s.B, s.P, s.verts, s.mv_mats, s.proj_mats, s.inv_mv_mats, s.inv_proj_mats, s.mats_transposed, s.verts_depth,
-        s.W, s.H, vproj, mats);
+        s.W, s.H, vproj, mats, counters, (uint32_t)ncounters);
 }
 
 void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int gx, int gy, int r0, int r1,

@@ -25,7 +25,9 @@ struct StageScope {
 };
 
 // ---- binning (dmr_binning.hip)
-void launch_project_verts(const dmr_scene& s, float4* vproj, float* mats, hipStream_t st);
+// also zeroes counters[0, ncounters) (tile_count | tile_hits)
+void launch_project_verts(const dmr_scene& s, float4* vproj, float* mats, uint32_t* counters, size_t ncounters,
+                          hipStream_t st);
 void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int gx, int gy, int r0, int r1,
                         uint2* face_rect, float* key_depth, float* max_depth, uint32_t* tiles_touched,
                         uint32_t* tile_count, hipStream_t st);
