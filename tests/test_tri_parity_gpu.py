@@ -21,6 +21,8 @@ CASES = {
     "C1_opaque": (4, 17, 1, 256, 256, (0.5, 0.95)),         # exercises early termination (T < 1e-4)
     "ragged": (3, 12, 2, 200, 328, (0.1, 0.6)),             # W, H not multiples of 16; two views
     "dense": (12, 9, 1, 64, 64, (0.05, 0.3)),               # long tile lists: several LDS chunks per tile
+    # 5120 faces over 4 tiles: lists longer than the sort's LDS capacity (in-place bitonic network in HBM), 40 chunks
+    "very_dense": (40, 9, 1, 32, 32, (0.01, 0.08)),
     # triangles far larger than the image, vertices far off-screen and behind the camera (mirrored by
     # clamp_w, Q2): exercises whole-tile coverage, the non-"near" / 32-bit coverage paths and int32 wrap (Q7)
     "huge": (3, 4, 2, 96, 144, (0.1, 0.4)),
