@@ -67,74 +67,76 @@ k_project_verts(int B, int P, const float* __restrict__ verts, const float* __re
 }
 
 // ---------------------------------------------------------------------------
-// 2. per (view, face): cull, tile rect, sort depth; count the face into every tile of its rect.
-//    rect is kept (packed 4 x u16) so the scatter pass does not redo the float work.
-// ---------------------------------------------------------------------------
-template <bool TET>
-__global__ void __launch_bounds__(256)
-k_setup_faces(int B, int P, int F, const int* __restrict__ faces, const float4* __restrict__ vproj,
-              int gx, int gy, int r0, int r1,
-              uint2* __restrict__ face_rect, float* __restrict__ key_depth, float* __restrict__ max_depth,
-              uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * F) return;
-    const int b = (int)(idx / F), f = (int)(idx % F);
-    const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
-    const float4 a0 = vproj[(int64_t)b * P + v0], a1 = vproj[(int64_t)b * P + v1], a2 = vproj[(int64_t)b * P + v2];
-    float max_z = a0.z, min_z = a0.z, depth = 0.0f;
-    depth += a0.z;
-    max_z = fmaxf(max_z, a1.z); min_z = fminf(min_z, a1.z); depth += a1.z;
-    max_z = fmaxf(max_z, a2.z); min_z = fminf(min_z, a2.z); depth += a2.z;
-    depth = depth / 3.0f;
-    uint32_t touched = 0;
-    Rect r = {0, 0, 0, 0};
-    if (!(max_z < -1.0f || min_z > 1.0f)) {
-        r = tile_rect({a0.x, a0.y}, {a1.x, a1.y}, {a2.x, a2.y}, gx, gy, r0, r1);
-        touched = (r.maxy - r.miny) * (r.maxx - r.minx);
-    }
-    if (touched == 0) r = {0, 0, 0, 0};
-    auto map01 = [](float z) { float d = (z + 1.0f) * 0.5f; if (d < 0.0f) d = 0.0f; if (d > 1.0f) d = 1.0f; return d; };
-    tiles_touched[idx] = touched;
-    face_rect[idx] = make_uint2(r.minx | (r.miny << 16), r.maxx | (r.maxy << 16));
-    // sort depth: tri = mean z (forward.cu:146-148), tet = min z (renderer_impl.cu:325); 0 when culled
-    key_depth[idx] = touched ? (TET ? map01(min_z) : map01(depth)) : 0.0f;
-    if (TET) max_depth[idx] = touched ? map01(max_z) : 0.0f;
-    if (touched) {
-        uint32_t* cnt = tile_count + (size_t)b * gx * gy;
-        for (uint32_t y = r.miny; y < r.maxy; y++)
-            for (uint32_t x = r.minx; x < r.maxx; x++) atomicAdd(&cnt[y * gx + x], 1u);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// 2b/4b. LDS-privatised variants, used when all B * tiles counters fit in LDS (<= LDS_HIST_MAX).
+// 2 / 4. per (view, face): cull, tile rect, sort depth, count the face into every tile of its rect (setup);
+//   scatter every (face, tile) pair into its tile's segment, key = depth_bits << 32 | face_id (scatter).
+//   rect is kept (packed 4 x u16) so the scatter pass does not redo the float work.
 //   Global u32 atomics on ~3000 hot tile counters were the cost of both passes (69 + 80 us at C4 for
-//   0.9 M increments).  Here a workgroup takes BIN_FACES consecutive faces, counts them into an LDS
-//   histogram (ds_add_u32), and touches global memory once per (workgroup, non-empty tile): the count
+//   0.9 M increments; 0.46 + 0.65 ms at C5).  Here a workgroup takes BIN_FACES consecutive faces, counts them
+//   into an LDS histogram (ds_add_u32), and touches global memory once per (workgroup, non-empty tile): the count
 //   pass adds the bin, the scatter pass reserves the bin's slots with ONE returning atomic and then hands
-//   out slots with returning LDS atomics.  Faces with huge rects bypass the histogram.
+//   out slots with returning LDS atomics.  The histogram covers a WINDOW of tiles: the bounding box of the
+//   workgroup's face rects in the view of its first face (consecutive faces of a mesh are neighbours on screen, so
+//   the box is a few hundred tiles even when the image has a million).  Faces with huge rects, faces of another
+//   view and whole workgroups whose box exceeds LDS_HIST_MAX tiles use the global counters directly.
 // ---------------------------------------------------------------------------
-constexpr int LDS_HIST_MAX = 16384;   // 64 KiB of counters
+constexpr int LDS_HIST_MAX = 8192;    // 32 KiB of counters
 constexpr int BIN_FACES = 1024;       // faces per workgroup (4 per thread)
 constexpr uint32_t BIG_RECT = 256;    // tiles; larger rects go straight to global atomics
+
+struct BinWindow { int x0, y0, wx, wy, view; bool lds; };
+
+// s_box: {min x, min y, max x, max y} of the rects that want the LDS histogram; uniform result.  Threads reduce
+// their own faces, waves reduce with shuffles, one lane per wave touches LDS (every thread doing ds_min / ds_max on
+// the same four words serialises: 2 cycles per lane and atomic).
+__device__ __forceinline__ BinWindow bin_window(int* s_box, int view, const uint2* rr, const uint32_t* touched,
+                                                const bool* mine, int tid) {
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = 0, by1 = 0;
+#pragma unroll
+    for (int it = 0; it < BIN_FACES / 256; it++) {
+        if (!mine[it] || touched[it] == 0 || touched[it] > BIG_RECT) continue;
+        bx0 = min(bx0, (int)(rr[it].x & 0xffffu)); by0 = min(by0, (int)(rr[it].x >> 16));
+        bx1 = max(bx1, (int)(rr[it].y & 0xffffu)); by1 = max(by1, (int)(rr[it].y >> 16));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, d, 64)); by0 = min(by0, __shfl_xor(by0, d, 64));
+        bx1 = max(bx1, __shfl_xor(bx1, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
+    }
+    if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = 0; s_box[3] = 0; }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0); atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
+    }
+    __syncthreads();
+    BinWindow w;
+    w.x0 = s_box[0]; w.y0 = s_box[1]; w.wx = s_box[2] - s_box[0]; w.wy = s_box[3] - s_box[1]; w.view = view;
+    w.lds = w.wx > 0 && w.wy > 0 && (int64_t)w.wx * w.wy <= LDS_HIST_MAX;
+    if (!w.lds) { w.wx = 0; w.wy = 0; }
+    return w;
+}
 
 template <bool TET>
 __global__ void __launch_bounds__(256)
 k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const float4* __restrict__ vproj,
-                  int gx, int gy, int r0, int r1, int ntiles,
+                  int gx, int gy, int r0, int r1,
                   uint2* __restrict__ face_rect, float* __restrict__ key_depth, float* __restrict__ max_depth,
                   uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count) {
-    extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_hist[LDS_HIST_MAX];
+    __shared__ int s_box[4];
     const int tid = threadIdx.x;
-    for (int t = tid; t < ntiles; t += 256) s_hist[t] = 0u;
-    __syncthreads();
     const int64_t BF = (int64_t)B * F;
     const int64_t base = (int64_t)blockIdx.x * BIN_FACES;
+    const int view = (int)(base / F);
+    uint2 rr[BIN_FACES / 256];
+    uint32_t touched[BIN_FACES / 256];
+    bool mine[BIN_FACES / 256];  // face of the window's view
 #pragma unroll
     for (int it = 0; it < BIN_FACES / 256; it++) {
         const int64_t idx = base + it * 256 + tid;
-        if (idx >= BF) break;
+        touched[it] = 0u; rr[it] = make_uint2(0, 0); mine[it] = false;
+        if (idx >= BF) continue;
         const int b = (int)(idx / F), f = (int)(idx % F);
+        mine[it] = b == view;
         const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
         const float4 a0 = vproj[(int64_t)b * P + v0], a1 = vproj[(int64_t)b * P + v1], a2 = vproj[(int64_t)b * P + v2];
         float max_z = a0.z, min_z = a0.z, depth = 0.0f;
@@ -142,70 +144,84 @@ k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const floa
         max_z = fmaxf(max_z, a1.z); min_z = fminf(min_z, a1.z); depth += a1.z;
         max_z = fmaxf(max_z, a2.z); min_z = fminf(min_z, a2.z); depth += a2.z;
         depth = depth / 3.0f;
-        uint32_t touched = 0;
         Rect r = {0, 0, 0, 0};
         if (!(max_z < -1.0f || min_z > 1.0f)) {
             r = tile_rect({a0.x, a0.y}, {a1.x, a1.y}, {a2.x, a2.y}, gx, gy, r0, r1);
-            touched = (r.maxy - r.miny) * (r.maxx - r.minx);
+            touched[it] = (r.maxy - r.miny) * (r.maxx - r.minx);
         }
-        if (touched == 0) r = {0, 0, 0, 0};
+        if (touched[it] == 0) r = {0, 0, 0, 0};
         auto map01 = [](float z) { float d = (z + 1.0f) * 0.5f; if (d < 0.0f) d = 0.0f; if (d > 1.0f) d = 1.0f; return d; };
-        tiles_touched[idx] = touched;
-        face_rect[idx] = make_uint2(r.minx | (r.miny << 16), r.maxx | (r.maxy << 16));
-        key_depth[idx] = touched ? (TET ? map01(min_z) : map01(depth)) : 0.0f;
-        if (TET) max_depth[idx] = touched ? map01(max_z) : 0.0f;
-        if (touched) {
-            const uint32_t tb = (uint32_t)b * gx * gy;
-            if (touched <= BIG_RECT) {
-                for (uint32_t y = r.miny; y < r.maxy; y++)
-                    for (uint32_t x = r.minx; x < r.maxx; x++) atomicAdd(&s_hist[tb + y * gx + x], 1u);
-            } else {
-                for (uint32_t y = r.miny; y < r.maxy; y++)
-                    for (uint32_t x = r.minx; x < r.maxx; x++) atomicAdd(&tile_count[tb + y * gx + x], 1u);
-            }
+        rr[it] = make_uint2(r.minx | (r.miny << 16), r.maxx | (r.maxy << 16));
+        tiles_touched[idx] = touched[it];
+        face_rect[idx] = rr[it];
+        key_depth[idx] = touched[it] ? (TET ? map01(min_z) : map01(depth)) : 0.0f;
+        if (TET) max_depth[idx] = touched[it] ? map01(max_z) : 0.0f;
+    }
+    const BinWindow w = bin_window(s_box, view, rr, touched, mine, tid);
+    const int nw = w.wx * w.wy;
+    for (int t = tid; t < nw; t += 256) s_hist[t] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < BIN_FACES / 256; it++) {
+        if (touched[it] == 0) continue;
+        const int64_t idx = base + it * 256 + tid;
+        const uint32_t tb = (uint32_t)(idx / F) * gx * gy;
+        const uint32_t minx = rr[it].x & 0xffffu, miny = rr[it].x >> 16, maxx = rr[it].y & 0xffffu, maxy = rr[it].y >> 16;
+        if (w.lds && mine[it] && touched[it] <= BIG_RECT) {
+            for (uint32_t y = miny; y < maxy; y++)
+                for (uint32_t x = minx; x < maxx; x++) atomicAdd(&s_hist[(y - w.y0) * w.wx + (x - w.x0)], 1u);
+        } else {
+            for (uint32_t y = miny; y < maxy; y++)
+                for (uint32_t x = minx; x < maxx; x++) atomicAdd(&tile_count[tb + y * gx + x], 1u);
         }
     }
     __syncthreads();
-    for (int t = tid; t < ntiles; t += 256) {
-        const uint32_t c = s_hist[t];
-        if (c) atomicAdd(&tile_count[t], c);
-    }
+    for (int y = tid / 64; y < w.wy; y += 4)
+        for (int x = tid % 64; x < w.wx; x += 64) {
+            const uint32_t c = s_hist[y * w.wx + x];
+            if (c) atomicAdd(&tile_count[(uint32_t)view * gx * gy + (uint32_t)(w.y0 + y) * gx + (uint32_t)(w.x0 + x)], c);
+        }
 }
 
 __global__ void __launch_bounds__(256)
-k_scatter_faces_lds(int B, int F, int gx, int gy, int ntiles, const uint2* __restrict__ face_rect,
+k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face_rect,
                     const float* __restrict__ key_depth, const uint32_t* __restrict__ tiles_touched,
                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys, uint32_t capacity) {
-    extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_hist[LDS_HIST_MAX];
+    __shared__ int s_box[4];
     const int tid = threadIdx.x;
-    for (int t = tid; t < ntiles; t += 256) s_hist[t] = 0u;
-    __syncthreads();
     const int64_t BF = (int64_t)B * F;
     const int64_t base = (int64_t)blockIdx.x * BIN_FACES;
+    const int view = (int)(base / F);
     uint2 rr[BIN_FACES / 256];
     uint32_t touched[BIN_FACES / 256];
+    bool mine[BIN_FACES / 256];
 #pragma unroll
     for (int it = 0; it < BIN_FACES / 256; it++) {
         const int64_t idx = base + it * 256 + tid;
         touched[it] = idx < BF ? tiles_touched[idx] : 0u;
         rr[it] = touched[it] ? face_rect[idx] : make_uint2(0, 0);
+        mine[it] = idx < BF && (int)(idx / F) == view;
     }
-    // pass 1: count this workgroup's entries per tile
+    const BinWindow w = bin_window(s_box, view, rr, touched, mine, tid);
+    const int nw = w.wx * w.wy;
+    for (int t = tid; t < nw; t += 256) s_hist[t] = 0u;
+    __syncthreads();
+    // pass 1: count this workgroup's entries per tile of the window
 #pragma unroll
     for (int it = 0; it < BIN_FACES / 256; it++) {
-        if (touched[it] == 0 || touched[it] > BIG_RECT) continue;
-        const int64_t idx = base + it * 256 + tid;
-        const uint32_t tb = (uint32_t)(idx / F) * gx * gy;
+        if (!(w.lds && mine[it]) || touched[it] == 0 || touched[it] > BIG_RECT) continue;
         const uint32_t minx = rr[it].x & 0xffffu, miny = rr[it].x >> 16, maxx = rr[it].y & 0xffffu, maxy = rr[it].y >> 16;
         for (uint32_t y = miny; y < maxy; y++)
-            for (uint32_t x = minx; x < maxx; x++) atomicAdd(&s_hist[tb + y * gx + x], 1u);
+            for (uint32_t x = minx; x < maxx; x++) atomicAdd(&s_hist[(y - w.y0) * w.wx + (x - w.x0)], 1u);
     }
     __syncthreads();
     // reserve the workgroup's slots of every non-empty tile with one returning atomic; the bin now holds the cursor
-    for (int t = tid; t < ntiles; t += 256) {
-        const uint32_t c = s_hist[t];
-        if (c) s_hist[t] = atomicAdd(&tile_cursor[t], c);
-    }
+    for (int y = tid / 64; y < w.wy; y += 4)
+        for (int x = tid % 64; x < w.wx; x += 64) {
+            const uint32_t c = s_hist[y * w.wx + x];
+            if (c) s_hist[y * w.wx + x] = atomicAdd(&tile_cursor[(uint32_t)view * gx * gy + (uint32_t)(w.y0 + y) * gx + (uint32_t)(w.x0 + x)], c);
+        }
     __syncthreads();
     // pass 2: hand out slots
 #pragma unroll
@@ -216,11 +232,11 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, int ntiles, const uint2* __res
         const uint32_t tb = (uint32_t)(idx / F) * gx * gy;
         const uint32_t minx = rr[it].x & 0xffffu, miny = rr[it].x >> 16, maxx = rr[it].y & 0xffffu, maxy = rr[it].y >> 16;
         const uint64_t key = ((uint64_t)__float_as_uint(key_depth[idx]) << 32) | (uint32_t)f;
-        const bool big = touched[it] > BIG_RECT;
+        const bool direct = !(w.lds && mine[it]) || touched[it] > BIG_RECT;
         for (uint32_t y = miny; y < maxy; y++)
             for (uint32_t x = minx; x < maxx; x++) {
-                const uint32_t t = tb + y * gx + x;
-                const uint32_t slot = big ? atomicAdd(&tile_cursor[t], 1u) : atomicAdd(&s_hist[t], 1u);
+                const uint32_t slot = direct ? atomicAdd(&tile_cursor[tb + y * gx + x], 1u)
+                                             : atomicAdd(&s_hist[(y - w.y0) * w.wx + (x - w.x0)], 1u);
                 if (slot < capacity) keys[slot] = key;
             }
     }
@@ -368,28 +384,6 @@ k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// 4. scatter every (face, tile) pair into its tile's segment: key = depth_bits << 32 | face_id
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_scatter_faces(int B, int F, int gx, int gy, const uint2* __restrict__ face_rect,
-                const float* __restrict__ key_depth, const uint32_t* __restrict__ tiles_touched,
-                uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys, uint32_t capacity) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * F) return;
-    if (tiles_touched[idx] == 0) return;  // Q25: a culled face emits nothing
-    const int b = (int)(idx / F), f = (int)(idx % F);
-    const uint2 rr = face_rect[idx];
-    const uint32_t minx = rr.x & 0xffffu, miny = rr.x >> 16, maxx = rr.y & 0xffffu, maxy = rr.y >> 16;
-    const uint64_t key = ((uint64_t)__float_as_uint(key_depth[idx]) << 32) | (uint32_t)f;
-    uint32_t* cur = tile_cursor + (size_t)b * gx * gy;
-    for (uint32_t y = miny; y < maxy; y++)
-        for (uint32_t x = minx; x < maxx; x++) {
-            uint32_t slot = atomicAdd(&cur[y * gx + x], 1u);
-            if (slot < capacity) keys[slot] = key;
-        }
-}
-
-// ---------------------------------------------------------------------------
 // 5. per-tile sort by (depth_bits, face_id).  One 256-thread workgroup per (view, tile).
 //    Normalised bitonic network (every compare-exchange ascending): with the segment
 //    virtually padded by +inf to a power of two, exchanges whose upper index is >= n are
@@ -516,26 +510,14 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
                         uint32_t* tile_count, hipStream_t st) {
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
     StageScope t(DMR_STAGE_SETUP_FACES, st);
-    const int ntiles = s.B * gx * gy;
-    if (ntiles <= LDS_HIST_MAX) {
-        dim3 g2((unsigned)((n + BIN_FACES - 1) / BIN_FACES));
-        const size_t lds = sizeof(uint32_t) * (size_t)ntiles;
-        if (tet)
-            k_setup_faces_lds<true><<<g2, block, lds, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, ntiles, face_rect,
-                                                            key_depth, max_depth, tiles_touched, tile_count);
-        else
-            k_setup_faces_lds<false><<<g2, block, lds, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, ntiles, face_rect,
-                                                             key_depth, max_depth, tiles_touched, tile_count);
-        return;
-    }
+    dim3 grid((unsigned)((n + BIN_FACES - 1) / BIN_FACES)), block(256);
     if (tet)
-        k_setup_faces<true><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect,
-                                                    key_depth, max_depth, tiles_touched, tile_count);
+        k_setup_faces_lds<true><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect, key_depth,
+                                                        max_depth, tiles_touched, tile_count);
     else
-        k_setup_faces<false><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect,
-                                                     key_depth, max_depth, tiles_touched, tile_count);
+        k_setup_faces_lds<false><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect, key_depth,
+                                                         max_depth, tiles_touched, tile_count);
 }
 
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
@@ -556,13 +538,7 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
     StageScope t(DMR_STAGE_SCATTER, st);
-    const int ntiles = s.B * gx * gy;
-    if (ntiles <= LDS_HIST_MAX) {
-        k_scatter_faces_lds<<<dim3((unsigned)((n + BIN_FACES - 1) / BIN_FACES)), dim3(256), sizeof(uint32_t) * (size_t)ntiles, st>>>(
-            s.B, s.F, gx, gy, ntiles, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
-        return;
-    }
-    k_scatter_faces<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
+    k_scatter_faces_lds<<<dim3((unsigned)((n + BIN_FACES - 1) / BIN_FACES)), dim3(256), 0, st>>>(
         s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
 }
 
