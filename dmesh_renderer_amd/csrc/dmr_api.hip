@@ -50,7 +50,7 @@ struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* ti
 struct ImageState {
     uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_cursor; int* num_rendered;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits; uint32_t* hit_offset; unsigned long long* hit_total; uint32_t* tile_order;
+    uint32_t* tile_hits; uint32_t* scan_tmp; uint32_t* hit_offset; unsigned long long* hit_total; uint32_t* tile_order;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
     int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
@@ -75,8 +75,9 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
     Carver c(b);
     s.mats = c.take<float>(64 * B);
     s.seed = c.take<int>(1);
-    // counters, zeroed by ONE memset at the start of a forward: [tile_count | tile_hits]
+    // counters, zeroed by k_project_verts at the start of a forward: [tile_count | tile_hits | scan_tmp's buckets]
     s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles);
+    s.scan_tmp = c.take<uint32_t>(dmr::scan_tmp_words((int)ntiles));
     s.hit_offset = c.take<uint32_t>(ntiles + 1); s.hit_total = c.take<unsigned long long>(1);
     s.tile_offset = c.take<uint32_t>(ntiles + 1);
     s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(1);
@@ -178,10 +179,10 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
 
     auto front = [&]() -> int {
         // (tile_count | tile_hits are contiguous: zeroed by k_project_verts, a slice per block)
-        dmr::launch_project_verts(*s, ps.vproj, is.mats, is.tile_count, (size_t)(is.tile_hits + d.ntiles - is.tile_count), st);
+        dmr::launch_project_verts(*s, ps.vproj, is.mats, is.tile_count, (size_t)(is.scan_tmp + dmr::SCAN_TMP_BUCKETS - is.tile_count), st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
-        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, is.tile_order, st);
+        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, is.tile_order, is.scan_tmp, st);
         return 0;
     };
     auto rest = [&](uint64_t capacity) -> int {
@@ -378,7 +379,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         auto it = g_size_cache.find(key);
         if (it != g_size_cache.end() && it->second.hits) guess = std::min<uint64_t>(padded(it->second.hits), 0xfffffffeull);
     }
-    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, host_total, st);
+    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, host_total, is.scan_tmp, st);
     DMR_HIP(hipEventRecord(sr->ev, st));
     if (guess && rest(guess)) return 1;
     DMR_HIP(hipEventSynchronize(sr->ev));

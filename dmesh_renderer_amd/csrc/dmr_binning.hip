@@ -347,6 +347,123 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
     if (tid == 0) { tile_offset[n] = wave_sum[16]; *num_rendered = (int)wave_sum[16]; *host_num_rendered = (int)wave_sum[16]; }
 }
 
+// ---- the same for many tiles (B * tiles > SCAN_SINGLE_MAX: several views at 1080p, 4096^2 images): one workgroup
+// per 8192 tiles, three small launches (partial sums + bucket sizes | scan of the partials | offsets + order) instead
+// of one workgroup streaming everything (0.5 ms for C5's 1 M tiles).
+constexpr int SCAN_BLOCK_TILES = 8192;
+constexpr int SCAN_SINGLE_MAX = 16384;   // up to here one workgroup does it all (k_scan_tiles)
+
+// pass 1: blk_sum[block] = sum of the block's counts; bucket_count[b] += tiles of the block in order bucket b
+template <bool ORDER>
+__global__ void __launch_bounds__(1024)
+k_scan_tiles_partial(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ blk_sum,
+                     uint32_t* __restrict__ bucket_count) {
+    __shared__ uint32_t wave_sum[17];
+    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int begin = min(n, (int)blockIdx.x * SCAN_BLOCK_TILES + tid * SCAN_BATCH), end = min(n, begin + SCAN_BATCH);
+    if (tid <= ORDER_BUCKETS) bucket[tid] = 0u;
+    __syncthreads();
+    uint32_t c[SCAN_BATCH], local = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) c[j] = begin + j < end ? tile_count[begin + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        local += c[j];
+        if (ORDER) {
+            const bool empty = begin + j < end && c[j] == 0u;
+            const uint64_t em = __ballot(empty);
+            if (em && lane == __ffsll((long long)em) - 1) atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
+            if (begin + j < end && c[j]) atomicAdd(&bucket[order_bucket(c[j])], 1u);
+        }
+    }
+    block_exclusive_scan(local, tid, wave_sum);
+    if (tid == 0) blk_sum[blockIdx.x] = wave_sum[16];
+    if (ORDER && tid <= ORDER_BUCKETS && bucket[tid]) atomicAdd(&bucket_count[tid], bucket[tid]);
+}
+
+// pass 2 (one workgroup): blk_sum -> exclusive scan in place, total -> R; bucket_count -> exclusive scan in place
+// (bucket 0 = longest lists first, empty tiles last): the cursors pass 3 claims from
+__global__ void __launch_bounds__(1024)
+k_scan_tiles_blocks(int nblk, int n, uint32_t* __restrict__ blk_sum, uint32_t* __restrict__ bucket_count,
+                    uint32_t* __restrict__ tile_offset, int* __restrict__ num_rendered, int* __restrict__ host_num_rendered,
+                    unsigned long long* __restrict__ total64, unsigned long long* __restrict__ host_total64) {
+    __shared__ uint32_t wave_sum[17];
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned long long carry = 0;  // the 32-bit offsets wrap harmlessly when the total does not fit (the host checks it)
+    for (int i0 = 0; i0 < nblk; i0 += 1024) {
+        const uint32_t v = i0 + tid < nblk ? blk_sum[i0 + tid] : 0u;
+        const uint32_t ex = block_exclusive_scan(v, tid, wave_sum);
+        if (i0 + tid < nblk) blk_sum[i0 + tid] = (uint32_t)carry + ex;
+        carry += wave_sum[16];
+        __syncthreads();  // wave_sum is reused
+    }
+    if (tid == 0) {
+        tile_offset[n] = (uint32_t)carry;
+        if (num_rendered) { *num_rendered = (int)carry; *host_num_rendered = (int)carry; }
+        if (total64) { *total64 = carry; *host_total64 = carry; }
+    }
+    if (bucket_count && tid < 128) {  // waves 0 and 1; only wave 0 holds buckets 0..63, the empty-tile bucket follows them
+        const uint32_t c = tid < ORDER_BUCKETS ? bucket_count[tid] : 0u;
+        uint32_t bi = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(bi, d, 64);
+            if (lane >= d) bi += o;
+        }
+        if (tid < ORDER_BUCKETS) bucket_count[tid] = bi - c;
+        if (tid == ORDER_BUCKETS - 1) bucket_count[ORDER_BUCKETS] = bi;
+    }
+}
+
+// pass 3: offsets, cursors and the order
+template <bool ORDER>
+__global__ void __launch_bounds__(1024)
+k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ blk_sum,
+                   uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
+                   uint32_t* __restrict__ tile_order) {
+    __shared__ uint32_t wave_sum[17];
+    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int begin = min(n, (int)blockIdx.x * SCAN_BLOCK_TILES + tid * SCAN_BATCH), end = min(n, begin + SCAN_BATCH);
+    if (tid <= ORDER_BUCKETS) bucket[tid] = 0u;
+    __syncthreads();
+    uint32_t c[SCAN_BATCH], local = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) c[j] = begin + j < end ? tile_count[begin + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        local += c[j];
+        if (ORDER) {
+            const bool empty = begin + j < end && c[j] == 0u;
+            const uint64_t em = __ballot(empty);
+            if (em && lane == __ffsll((long long)em) - 1) atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
+            if (begin + j < end && c[j]) atomicAdd(&bucket[order_bucket(c[j])], 1u);
+        }
+    }
+    uint32_t run = blk_sum[blockIdx.x] + block_exclusive_scan(local, tid, wave_sum);
+    // claim the block's share of every bucket of the global order; the LDS bins then hand out slots
+    if (ORDER && tid <= ORDER_BUCKETS) { const uint32_t cnt = bucket[tid]; bucket[tid] = cnt ? atomicAdd(&bucket_cursor[tid], cnt) : 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        const bool in = begin + j < end;
+        if (in) { tile_offset[begin + j] = run; if (ORDER) tile_cursor[begin + j] = run; }
+        run += c[j];
+        if (!ORDER) continue;
+        const bool empty = in && c[j] == 0u;
+        const uint64_t em = __ballot(empty);
+        uint32_t ebase = 0;
+        if (em) {
+            const int leader = __ffsll((long long)em) - 1;
+            if (lane == leader) ebase = atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
+            ebase = __shfl(ebase, leader, 64);
+        }
+        if (empty) tile_order[ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)(begin + j);
+        else if (in) tile_order[atomicAdd(&bucket[order_bucket(c[j])], 1u)] = (uint32_t)(begin + j);
+    }
+}
+
 // exclusive scan of the per-tile hit counts of the forward: every tile's region of the backward's record buffer
 // (u32 offsets; the total is < 2^32 or the backward fails) and the total
 __global__ void __launch_bounds__(1024)
@@ -521,15 +638,37 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
 }
 
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
-                       int* num_rendered, int* host_num_rendered, uint32_t* tile_order, hipStream_t st) {
+                       int* num_rendered, int* host_num_rendered, uint32_t* tile_order, uint32_t* scan_tmp, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
-    k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered, host_num_rendered, tile_order);
+    if (ntiles <= SCAN_SINGLE_MAX) {
+        k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered, host_num_rendered, tile_order);
+        return;
+    }
+    // scan_tmp: [ORDER_BUCKETS + 1 bucket counters, zeroed by k_project_verts | partial sums per block]
+    const int nblk = (ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES;
+    uint32_t* bucket = scan_tmp;
+    uint32_t* blk_sum = scan_tmp + SCAN_TMP_BUCKETS;
+    k_scan_tiles_partial<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, blk_sum, bucket);
+    k_scan_tiles_blocks<<<dim3(1), dim3(1024), 0, st>>>(nblk, ntiles, blk_sum, bucket, tile_offset, num_rendered, host_num_rendered,
+                                                        nullptr, nullptr);
+    k_scan_tiles_final<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, blk_sum, bucket, tile_offset, tile_cursor, tile_order);
 }
 
+size_t scan_tmp_words(int ntiles) { return SCAN_TMP_BUCKETS + (size_t)(ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES + 1; }
+
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
-                      unsigned long long* host_hit_total, hipStream_t st) {
+                      unsigned long long* host_hit_total, uint32_t* scan_tmp, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
-    k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, hit_offset, hit_total, host_hit_total);
+    if (ntiles <= SCAN_SINGLE_MAX) {
+        k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, hit_offset, hit_total, host_hit_total);
+        return;
+    }
+    const int nblk = (ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES;
+    uint32_t* blk_sum = scan_tmp + SCAN_TMP_BUCKETS;  // the forward's partial sums are no longer needed
+    k_scan_tiles_partial<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, blk_sum, nullptr);
+    k_scan_tiles_blocks<<<dim3(1), dim3(1024), 0, st>>>(nblk, ntiles, blk_sum, nullptr, hit_offset, nullptr, nullptr, hit_total,
+                                                        host_hit_total);
+    k_scan_tiles_final<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, blk_sum, nullptr, hit_offset, nullptr, nullptr);
 }
 
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,

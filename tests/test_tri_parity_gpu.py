@@ -23,6 +23,8 @@ CASES = {
     "dense": (12, 9, 1, 64, 64, (0.05, 0.3)),               # long tile lists: several LDS chunks per tile
     # 5120 faces over 4 tiles: lists longer than the sort's LDS capacity (in-place bitonic network in HBM), 40 chunks
     "very_dense": (40, 9, 1, 32, 32, (0.01, 0.08)),
+    # 2 x 96 x 96 = 18 432 tiles: the multi-workgroup tile scans (more than 16 384 tiles) and windowed binning
+    "many_tiles": (3, 24, 2, 1536, 1536, (0.1, 0.5)),
     # triangles far larger than the image, vertices far off-screen and behind the camera (mirrored by
     # clamp_w, Q2): exercises whole-tile coverage, the non-"near" / 32-bit coverage paths and int32 wrap (Q7)
     "huge": (3, 4, 2, 96, 144, (0.1, 0.4)),
