@@ -143,20 +143,23 @@ SizeRead* size_read() {
 
 // Speculative sizing.  The sizes of the binning buffer (R) and of the hit-record
 // buffer are only known on the device.  The reference stalls the pipeline on a device->host read before
-// it can continue (rasterizer_impl.cu:287-299).  Here the previous call with the same problem dimensions
-// provides a capacity guess (+25 %): the buffer is allocated and ALL remaining kernels are enqueued before
+// it can continue (rasterizer_impl.cu:287-299).  Here the previous call with the same view configuration
+// provides a capacity guess (its sizes per face / per list entry, +25 %): the buffer is allocated and ALL remaining kernels are enqueued before
 // the host waits -- and it waits on an event recorded right after the size copy, not on the stream, so the
 // GPU keeps running.  Kernels clamp their writes to the capacity; if the exact size turns out larger the
 // affected stages are simply enqueued again with an exact buffer (first call, or a scene that grew > 25 %).
+// The guess is keyed by the view configuration only and kept as RATIOS (list entries per face-view, hit records
+// per list entry): a mesh whose face count changes every iteration (DMesh re-tetrahedralises) still gets a guess,
+// and the cache stays a handful of entries.
 struct SizeKey {
-    int v[9];
+    int v[6];
     bool operator<(const SizeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
-struct SizeGuess { uint64_t rendered = 0, hits = 0; };
+struct SizeGuess { double rendered_per_face = 0.0, hits_per_rendered = 0.0; };
 std::mutex g_size_mu;
 std::map<SizeKey, SizeGuess> g_size_cache;
 SizeKey size_key(const dmr_scene* s, bool tet, const Dims& d) {
-    return SizeKey{{s->B, s->P, s->F, s->T, s->W, s->H, d.r0, d.r1, tet ? 1 : 0}};
+    return SizeKey{{s->B, s->W, s->H, d.r0, d.r1, tet ? 1 : 0}};
 }
 uint64_t padded(uint64_t n) { return n + n / 4 + 4096; }
 
@@ -204,7 +207,8 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
         auto it = g_size_cache.find(key);
-        if (it != g_size_cache.end() && it->second.rendered) guess = std::min<uint64_t>(padded(it->second.rendered), 0x7fffffffu);
+        if (it != g_size_cache.end() && it->second.rendered_per_face > 0.0)
+            guess = std::min<uint64_t>(padded((uint64_t)(it->second.rendered_per_face * (double)d.BF)), 0x7fffffffu);
     }
     if (front()) return 1;
     DMR_HIP(hipEventRecord(sr->ev, st));
@@ -221,7 +225,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
-        g_size_cache[key].rendered = (uint64_t)std::max(R, 1);
+        g_size_cache[key].rendered_per_face = (double)std::max(R, 1) / (double)std::max<size_t>(d.BF, 1);
     }
     DMR_HIP(hipGetLastError());
     return 0;
@@ -377,7 +381,8 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
         auto it = g_size_cache.find(key);
-        if (it != g_size_cache.end() && it->second.hits) guess = std::min<uint64_t>(padded(it->second.hits), 0xfffffffeull);
+        if (it != g_size_cache.end() && it->second.hits_per_rendered > 0.0)
+            guess = std::min<uint64_t>(padded((uint64_t)(it->second.hits_per_rendered * (double)num_rendered)), 0xfffffffeull);
     }
     dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, host_total, is.scan_tmp, st);
     DMR_HIP(hipEventRecord(sr->ev, st));
@@ -393,7 +398,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
-        g_size_cache[key].hits = std::max<uint64_t>(nhits, 1);
+        g_size_cache[key].hits_per_rendered = (double)std::max<uint64_t>(nhits, 1) / (double)num_rendered;
     }
     DMR_HIP(hipGetLastError());
     return 0;
