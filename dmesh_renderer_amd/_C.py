@@ -233,9 +233,13 @@ def render_tets(background, verts, faces, verts_color, faces_opacity, mv_mats, p
         call = _Call(dev, background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                      inv_proj_mats, verts_depth, faces_intense, image_height, image_width,
                      tets=tets, face_tets=face_tets, tet_faces=tet_faces, seed=ray_random_seed, rows=rows)
-        color = th.zeros((call.B, NUM_CHANNELS, call.H, call.W), dtype=th.float32, device=dev)
-        depth = th.zeros((call.B, 1, call.H, call.W), dtype=th.float32, device=dev)
-        active = th.zeros((call.B, call.H, call.W), dtype=th.float32, device=dev)
+        # k_tet_forward writes every pixel of the rendered rows (background where the march fails); zero-fill
+        # (render.cu:287-290) is only needed when a band leaves rows untouched or nothing is launched
+        full = tuple(rows) == (0, 0) and call.P > 0 and call.F > 0
+        alloc_img = th.empty if full else th.zeros
+        color = alloc_img((call.B, NUM_CHANNELS, call.H, call.W), dtype=th.float32, device=dev)
+        depth = alloc_img((call.B, 1, call.H, call.W), dtype=th.float32, device=dev)
+        active = alloc_img((call.B, call.H, call.W), dtype=th.float32, device=dev)
         rendered = C.c_int(0)
         rc = lib.dmr_tet_forward(C.byref(call.scene), color.data_ptr(), depth.data_ptr(), active.data_ptr(),
                                  call.alloc, None, call.stream(), C.byref(rendered))

@@ -93,7 +93,8 @@ int dmr_tri_backward(const dmr_scene* scene, const float* dL_dcolor, const float
                      float* dL_dvdepth, float* dL_dfintense,
                      dmr_alloc_fn alloc, void* alloc_ctx, void* stream);
 
-/* out_active [B,H,W]: 1.0 where the ray marched to a valid end, else 0.0. */
+/* out_active [B,H,W]: 1.0 where the ray marched to a valid end, else 0.0.  Like the tri forward, every pixel of the
+ * rendered tile rows of all three outputs is written (background / 1 / 0 where the march fails). */
 int dmr_tet_forward(const dmr_scene* scene, float* out_color, float* out_depth, float* out_active,
                     dmr_alloc_fn alloc, void* alloc_ctx, void* stream, int* num_rendered);
 
