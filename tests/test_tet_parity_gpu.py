@@ -123,3 +123,26 @@ def test_seeded_jitter(oracle, hip_device):
             assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (seed, key)
         imgs[seed] = out[0].cpu().numpy()
     assert np.abs(imgs[7] - imgs[0]).max() > 1e-3 and np.abs(imgs[7] - imgs[8]).max() > 1e-3
+
+
+def test_empty_inputs(hip_device):
+    """No faces / no tets / no vertices (Q17: the reference has no guards here): background image, inactive pixels,
+    zero gradients, no out-of-bounds access."""
+    from dmesh_renderer_amd import _C
+    dev = hip_device
+    d, B, H, W = _scene("small")
+    for P, F, T in ((0, 0, 0), (d["verts"].shape[0], 0, 0)):
+        dd = dict(d)
+        dd["verts"] = d["verts"][:P]; dd["verts_color"] = d["verts_color"][:P]; dd["verts_depth"] = d["verts_depth"][:, :P]
+        dd["faces"] = d["faces"][:F]; dd["faces_opacity"] = d["faces_opacity"][:F]; dd["faces_intense"] = d["faces_intense"][:, :F]
+        dd["face_tets"] = d["face_tets"][:F]; dd["tets"] = d["tets"][:T]; dd["tet_faces"] = d["tet_faces"][:T]
+        args = c_args(dd, dev, tet=True)
+        out = _C.render_tets(*args, H, W, 0)
+        th.cuda.synchronize()
+        bg = dd["bg"].to(dev)
+        assert float(out[2].abs().max()) == 0.0
+        assert th.equal(out[0], bg.view(1, 3, 1, 1).expand(B, 3, H, W).contiguous()) or float(out[0].abs().max()) == 0.0
+        g = _C.render_tets_backward(*args, th.ones(B, 3, H, W, device=dev), th.ones(B, 1, H, W, device=dev), *out[3:7])
+        th.cuda.synchronize()
+        assert [tuple(x.shape) for x in g] == [(P, 3), (F,)]
+        assert all(float(x.abs().sum()) == 0.0 for x in g)
