@@ -232,13 +232,4 @@ __device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int
     return e;
 }
 
-__device__ __forceinline__ bool edge_inside(const int32_t* s0, const int32_t* bx, const int32_t* by, int lx, int ly) {
-    uint32_t s1 = (uint32_t)s0[0] + (uint32_t)bx[0] * (uint32_t)lx + (uint32_t)by[0] * (uint32_t)ly;
-    uint32_t s2 = (uint32_t)s0[1] + (uint32_t)bx[1] * (uint32_t)lx + (uint32_t)by[1] * (uint32_t)ly;
-    uint32_t s3 = (uint32_t)s0[2] + (uint32_t)bx[2] * (uint32_t)lx + (uint32_t)by[2] * (uint32_t)ly;
-    return (int32_t)(s1 & s2 & s3) < 0;
-}
-
-__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-
 }  // namespace dmr

@@ -3,25 +3,26 @@
 // Replaces TRI_FORWARD::renderCUDA (cuda_rasterizer/forward.cu:257-489) and
 // TRI_BACKWARD::renderCUDA (cuda_rasterizer/backward.cu:9-421).
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile; wave w owns the 8x8 pixel quadrant
-// (w & 1, w >> 1), lane l the pixel (l & 7, l >> 3) inside it.  The tile's depth-sorted face
-// list is consumed in chunks staged through LDS.  Per chunk each wave runs two phases:
+// One 256-thread workgroup (4 wave64) per 16x16 tile, tiles taken longest list first; wave w owns the 8x8 pixel
+// quadrant (w & 1, w >> 1), lane l the pixel (l & 7, l >> 3) inside it.  The tile's depth-sorted face list is
+// consumed in 128-face chunks staged through LDS (waves 0-1 build the coverage records, waves 2-3 the shading
+// records).  Per chunk:
 //
-//   A. coverage  -- the face index is wave-uniform: every lane evaluates the three
-//      fixed-point edge functions of face j for its own pixel from a 40-byte LDS record
-//      (broadcast reads) and records the result as bit j of a per-lane bit mask.  All the
-//      per-face work of the reference's in_tri (float->fixed conversion, winding swap, edge
-//      deltas, top-left bias) was done once when the face was staged.
-//   B. shading   -- every lane walks the set bits of ITS OWN mask in list order, so all
-//      64 lanes do useful blending work on (generally different) faces at once instead of
-//      a few lanes per face; face records are gathered from LDS with per-lane addresses
-//      (112-byte stride = odd number of 16-byte slots, conflict-light for ds_read_b128).
+//   A. coverage  -- face-parallel: 256 / CHUNK threads rasterise one staged face each over the rows of its
+//      tile-local pixel box, stepping the three fixed-point edge functions incrementally, and OR the face's bit
+//      into the covered pixels' mask words in LDS (ds_or_b32 runs at full rate).  All the per-face work of the
+//      reference's in_tri (float->fixed conversion, winding swap, edge deltas, top-left bias) was done once when
+//      the face was staged.
+//   B. shading   -- every lane walks the set bits of ITS OWN mask in list order, so all 64 lanes do useful
+//      blending work on (generally different) faces at once instead of a few lanes per face; face records are
+//      gathered from LDS with per-lane addresses (112-byte stride = odd number of 16-byte slots, conflict-light
+//      for ds_read_b128).
 //
-// The pixel's result is the same sequence of blends as the reference's loop.  Rays are
-// recomputed per pixel (not stored).  The backward walks the chunks from the back, adds each
-// hit's 23 gradient components into per-face LDS accumulators (ds_add_f32), and flushes a
-// chunk with packed atomics: 3 vertex rows + 1 face row per (tile, face) instead of the
-// reference's 23 global atomics per (pixel, face).
+// The pixel's result is the same sequence of blends as the reference's loop.  Rays are recomputed per pixel (not
+// stored).  The backward is two kernels: k_tri_backward_pix (same layout, chunks from the back: the per-pixel
+// sequential part, one 16-byte record per blended pair, face-major) and k_tri_backward_hits (one lane per record:
+// the 23 gradient components, segmented DPP scan, workgroup LDS tables, packed atomics).  DESIGN.md section 5 has the
+// measurements behind every step.
 #include <algorithm>
 #include <cstdlib>
 
@@ -29,9 +30,6 @@
 
 namespace dmr {
 
-#ifndef DMR_COV_UNROLL
-#define DMR_COV_UNROLL 1
-#endif
 constexpr int FWD_CHUNK = 128;
 #ifndef DMR_BWD_CHUNK
 #define DMR_BWD_CHUNK 128
@@ -292,22 +290,14 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 // ---------------------------------------------------------------------------
 constexpr int NACC = 23;  // 9 dverts, 9 dvcolor, 3 dvdepth, dopacity, dintense
 
-// DPP lane moves (VALU, no LDS traffic).  dpp_i: a lane whose source is outside its 16-lane row
-// (row_shr) or outside the written rows (row_bcast, row_mask) keeps `old`.  dpp_f_any: same move, but the
-// value of such lanes is unspecified (callers ignore it) -- no register initialisation, no hazard nops.
+// DPP lane move (VALU, no LDS traffic): a lane whose source is outside its 16-lane row keeps `old`.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f_any(float src) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), CTRL, ROW_MASK, 0xF, true));
-}
 // 1-ulp reciprocal (v_rcp_f32): gradients are checked to 1e-4, the forward keeps IEEE division
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 constexpr int DPP_ROW_SHR = 0x110;      // + n, n = 1..15
-constexpr int DPP_ROW_BCAST15 = 0x142;  // lane 15 of each row -> every lane of the next row
-constexpr int DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
 
 // One level of the segmented inclusive scan over the 23 components: g += m * g[source lane], m = 1.0 where the
 // source lane carries the same list entry, else 0.0.  One v_fmac_f32_dpp per value (scripts/micro/valu_rates.hip:
@@ -338,9 +328,7 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
     if (CTRL == DPP_ROW_SHR + 1) DMR_SEG_LEVEL("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
     else if (CTRL == DPP_ROW_SHR + 2) DMR_SEG_LEVEL("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
     else if (CTRL == DPP_ROW_SHR + 4) DMR_SEG_LEVEL("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    else if (CTRL == DPP_ROW_SHR + 8) DMR_SEG_LEVEL("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    else if (CTRL == DPP_ROW_BCAST15) DMR_SEG_LEVEL("row_bcast:15 row_mask:0xa bank_mask:0xf bound_ctrl:0");
-    else DMR_SEG_LEVEL("row_bcast:31 row_mask:0xc bank_mask:0xf bound_ctrl:0");
+    else DMR_SEG_LEVEL("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
 }
 
 // ---------------------------------------------------------------------------
