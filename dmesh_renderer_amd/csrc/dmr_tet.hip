@@ -9,6 +9,8 @@
 // Rays are recomputed per pixel (seed <= 0 branch of generateRaysCUDA, forward.cu:124-127).
 // Guards: Q17 (no work when P/F/T == 0), Q18 (only pixels inside the image are touched),
 // Q19 (the unread is_active_backward diagnostic is dropped).
+#include <cstdlib>
+
 #include "dmr_kernels.hpp"
 
 namespace dmr {
@@ -24,7 +26,7 @@ struct alignas(16) TetColRec { float c0[3], c1[3], c2[3]; int v0, v1, v2; };
 static_assert(sizeof(TetColRec) == 48, "TetColRec");
 
 struct TetParams {
-    int B, P, F, W, H, gx, gy, r0;
+    int B, P, F, W, H, gx, gy, r0, dbg;
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* mv; const float* proj; const float* inv_mv; const float* inv_proj;
     const float* faces_intense; const float* bg;
@@ -422,7 +424,8 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
             const float g[10] = {i0 * dc0 * intense, i0 * dc1 * intense, i0 * dc2 * intense,
                                  i1 * dc0 * intense, i1 * dc1 * intense, i1 * dc2 * intense,
                                  i2 * dc0 * intense, i2 * dc1 * intense, i2 * dc2 * intense, dop};
-            const int slot = acc.find(curr_face);
+            // (DMR_ABLATE bit 2048, tests only: odd faces are refused a slot, which exercises the direct-atomic fallback)
+            const int slot = ((p.dbg & 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face);
             if (slot >= 0) {
 #pragma unroll
                 for (int c = 0; c < 10; c++) atomicAdd(&s_val[c][slot], (double)g[c]);
@@ -459,6 +462,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
 static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImageState img) {
     TetParams p;
     p.B = s.B; p.P = s.P; p.F = s.F; p.W = s.W; p.H = s.H; p.gx = gx; p.gy = gy; p.r0 = r0;
+    { static const int dbg = getenv("DMR_ABLATE") ? atoi(getenv("DMR_ABLATE")) : 0; p.dbg = dbg; }  // tests / timing ablations only
     p.verts = s.verts; p.faces = s.faces; p.verts_color = s.verts_color; p.faces_opacity = s.faces_opacity;
     p.mv = s.mv_mats; p.proj = s.proj_mats; p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats;
     p.faces_intense = s.faces_intense; p.bg = s.background;

@@ -657,7 +657,8 @@ __device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L
         const int sb = __float_as_int(row[27]);
         if (w < 3) {
             const uint32_t rid = (uint32_t)sb * (uint32_t)p.P + (uint32_t)__float_as_int(row[23 + w]);
-            const int slot = tab_find<VTAB>(L.vkey, rid);
+            // (DMR_ABLATE bit 2048, tests only: odd rows are refused a slot, which exercises the direct-atomic fallback)
+            const int slot = ((p.dbg & 2048) && (rid & 1u)) ? -1 : tab_find<VTAB>(L.vkey, rid);
             float v[7];
 #pragma unroll
             for (int c = 0; c < 3; c++) { v[c] = row[3 * w + c]; v[3 + c] = row[9 + 3 * w + c]; }
@@ -671,7 +672,7 @@ __device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L
             }
         } else {
             const uint32_t rid = (uint32_t)sb * (uint32_t)p.F + (uint32_t)__float_as_int(row[26]);
-            const int slot = tab_find<FTAB>(L.fkey, rid);
+            const int slot = ((p.dbg & 2048) && (rid & 1u)) ? -1 : tab_find<FTAB>(L.fkey, rid);
             if (slot >= 0) { atomicAdd(&L.fval[slot][0], (double)row[21]); atomicAdd(&L.fval[slot][1], (double)row[22]); }
             else { atomicAdd(&frow[(int64_t)rid * FROW], row[21]); atomicAdd(&frow[(int64_t)rid * FROW + 1], row[22]); }
         }

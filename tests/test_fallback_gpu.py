@@ -1,0 +1,51 @@
+"""The aggregation tables of the backward kernels (LDS hash tables in front of the global atomics) fall back to
+direct atomics when a row finds no slot.  Real scenes rarely get there, so a child process runs the library with
+DMR_ABLATE=2048 -- rows with an odd id are refused a slot -- and checks the gradients against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch as th
+from dmesh_renderer_amd import _C, scenes
+from dmesh_renderer_amd.scenes import c_args, rel_err, upstream_grads
+from oracle import oracle as O
+O.build()
+dev = th.device("cuda:0")
+B, H, W = 2, 200, 328
+d = scenes.layered_sheets(3, 12, B, H, W, seed=0)
+gc, gd = upstream_grads(B, H, W)
+args = c_args(d, dev)
+out = _C.render_tris(*args, H, W)
+g = _C.render_tris_backward(*args, gc.to(dev), gd.to(dev), out[0], *out[3:7])
+sc = O.scene_from_module_inputs(d, H, W)
+oc, od, ost = O.tri_forward(sc)
+og = O.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+for t, k in zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")):
+    assert rel_err(t.cpu().numpy(), og[k]) <= 1e-4, k
+d = scenes.kuhn_tets(5, 2, 120, 200)
+gc, gd = upstream_grads(2, 120, 200)
+args = c_args(d, dev, tet=True)
+out = _C.render_tets(*args, 120, 200, 0)
+g = _C.render_tets_backward(*args, gc.to(dev), gd.to(dev), *out[3:7])
+sc = O.scene_from_module_inputs(d, 120, 200)
+oc, od, oa, ost = O.tet_forward(sc)
+og = O.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+for t, k in zip(g, ("verts_color", "faces_opacity")):
+    assert rel_err(t.cpu().numpy(), og[k]) <= 1e-4, k
+print("fallback ok")
+"""
+
+
+def test_direct_atomic_fallbacks(hip_device):
+    env = dict(os.environ, DMR_ABLATE="2048")
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
