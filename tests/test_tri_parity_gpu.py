@@ -19,6 +19,7 @@ CASES = {
     # name: (layers, n, B, H, W, opacity)
     "C1": (4, 17, 1, 256, 256, (0.1, 0.5)),                 # BASELINE configs[0]
     "C1_opaque": (4, 17, 1, 256, 256, (0.5, 0.95)),         # exercises early termination (T < 1e-4)
+    "alpha_one": (4, 17, 1, 256, 256, (0.2, 0.6)),          # every 5th face has opacity exactly 1 (Q10's alpha == 1 branch)
     "ragged": (3, 12, 2, 200, 328, (0.1, 0.6)),             # W, H not multiples of 16; two views
     "dense": (12, 9, 1, 64, 64, (0.05, 0.3)),               # long tile lists: several LDS chunks per tile
     # 5120 faces over 4 tiles: lists longer than the sort's LDS capacity (in-place bitonic network in HBM), 40 chunks
@@ -36,6 +37,8 @@ def _make(case):
     d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
     if case == "huge":
         d["verts"] = d["verts"] * th.tensor([40.0, 40.0, 3.0])
+    if case == "alpha_one":
+        d["faces_opacity"][::5] = 1.0
     return d, B, H, W
 
 
