@@ -130,24 +130,30 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
 }
 
 // pinned (coherent, device-visible) landing pad the scan kernels write the sizes to, and the event the host
-// waits on; one per host thread
+// waits on; one per host thread and device (an event belongs to the device it was created on)
 struct SizeRead { void* slot = nullptr; hipEvent_t ev = nullptr; };
 SizeRead* size_read() {
-    thread_local SizeRead sr;
+    thread_local std::map<int, SizeRead> per_device;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SizeRead& sr = per_device[dev];
     if (!sr.slot) {
-        if (hipHostMalloc(&sr.slot, 64, hipHostMallocCoherent) != hipSuccess) { sr.slot = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&sr.slot, 64, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { sr.slot = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
+            (void)hipHostFree(sr.slot); sr.slot = nullptr; return nullptr;
+        }
     }
     return &sr;
 }
 
-// Speculative sizing.  The sizes of the binning buffer (R) and of the hit-record
-// buffer are only known on the device.  The reference stalls the pipeline on a device->host read before
-// it can continue (rasterizer_impl.cu:287-299).  Here the previous call with the same view configuration
-// provides a capacity guess (its sizes per face / per list entry, +25 %): the buffer is allocated and ALL remaining kernels are enqueued before
-// the host waits -- and it waits on an event recorded right after the size copy, not on the stream, so the
-// GPU keeps running.  Kernels clamp their writes to the capacity; if the exact size turns out larger the
-// affected stages are simply enqueued again with an exact buffer (first call, or a scene that grew > 25 %).
+// Speculative sizing.  The sizes of the binning buffer (R) and of the hit-record buffer are
+// only known on the device.  The reference stalls the pipeline on a device->host read before it can continue
+// (rasterizer_impl.cu:287-299).  Here the previous call with the same view configuration provides a capacity guess
+// (its sizes per face / per list entry, +25 %): the buffer is allocated and ALL remaining kernels are enqueued
+// before the host waits -- and it waits on an event recorded right behind the kernel that writes the size to
+// pinned host memory, not on the stream, so the GPU keeps running.  Kernels clamp their writes to the capacity; if
+// the exact size turns out larger the affected stages are simply enqueued again with an exact buffer (first call,
+// or a scene that grew by more than 25 %).
 // The guess is keyed by the view configuration only and kept as RATIOS (list entries per face-view, hit records
 // per list entry): a mesh whose face count changes every iteration (DMesh re-tetrahedralises) still gets a guess,
 // and the cache stays a handful of entries.
