@@ -55,7 +55,7 @@ struct ImageState {
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
     int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
 };
-struct BinningState { uint64_t* keys; uint32_t* face_list; };
+struct BinningState { uint64_t* keys; uint32_t* face_list; uint32_t capacity; };
 
 size_t carve_point(void* b, size_t BP, PointState& s) { Carver c(b); s.vproj = c.take<float4>(BP); return c.off; }
 size_t carve_face(void* b, size_t BF, size_t F, size_t T, bool tet, FaceState& s) {
@@ -97,6 +97,7 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
 size_t carve_binning(void* b, size_t R, BinningState& s) {
     Carver c(b);
     s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
+    s.capacity = (uint32_t)std::min<size_t>(R, 0xffffffffu);
     return c.off;
 }
 
@@ -202,7 +203,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (capacity > 0) {
             dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
                                       (uint32_t)capacity, st);
-            dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, st);
+            dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, bs.capacity, st);
         }
         render(bs);
         return 0;
@@ -320,7 +321,7 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     auto render = [&](const BinningState& bs) {
         dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_order};
         const dmr_scene sc = canonical(s, is.mats);
-        dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img, out_color,
+        dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, bs.capacity, img, out_color,
                                 out_depth, st);
     };
     return run_forward(s, false, d, alloc, ctx, st, ps, fs, is, num_rendered, render);
@@ -424,7 +425,7 @@ int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, floa
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tet_prep(sc, img, st);
         dmr::launch_tet_first_intersect(sc, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
-                                        bs.face_list, img, st);
+                                        bs.face_list, bs.capacity, img, st);
         dmr::launch_tet_forward(sc, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
     };
     return run_forward(s, true, d, alloc, ctx, st, ps, fs, is, num_rendered, render);

@@ -85,6 +85,29 @@ constexpr uint32_t BIG_RECT = 256;    // tiles; larger rects go straight to glob
 
 struct BinWindow { int x0, y0, wx, wy, view; bool lds; };
 
+// Faces whose rect covers more than BIG_RECT tiles (a ground plane, a hull face: up to every tile of the image) are
+// not emitted by their own thread -- one thread looping over 8160 tiles with (returning) atomics was 1.9 + 2.2 ms for
+// 64 screen-filling triangles at 800x800 (scripts/time_huge.py) -- but queued in LDS and emitted by the whole
+// workgroup, 256 tiles at a time.  The queue holds BIG_MAX faces; further ones fall back to their own thread.
+constexpr int BIG_MAX = 128;
+struct BigFace { uint32_t rect_lo, rect_hi, tile_base, key_lo, key_hi; };
+
+// tiles i = tid, tid + 256, ... of a rect in row-major order, without a division per tile
+struct RectWalk {
+    uint32_t w, n, i, x, y, dx, dy;
+    __device__ __forceinline__ RectWalk(uint32_t minx, uint32_t miny, uint32_t maxx, uint32_t maxy, uint32_t tid) {
+        w = maxx - minx; n = w * (maxy - miny); i = tid;
+        y = miny + tid / w; x = minx + tid % w; dy = 256u / w; dx = 256u % w;
+        x0 = minx;
+    }
+    uint32_t x0;
+    __device__ __forceinline__ bool valid() const { return i < n; }
+    __device__ __forceinline__ void next() {
+        i += 256u; y += dy; x += dx;
+        if (x >= x0 + w) { x -= w; y++; }
+    }
+};
+
 // s_box: {min x, min y, max x, max y} of the rects that want the LDS histogram; uniform result.  Threads reduce
 // their own faces, waves reduce with shuffles, one lane per wave touches LDS (every thread doing ds_min / ds_max on
 // the same four words serialises: 2 cycles per lane and atomic).
@@ -123,7 +146,10 @@ k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const floa
                   uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count) {
     __shared__ uint32_t s_hist[LDS_HIST_MAX];
     __shared__ int s_box[4];
+    __shared__ BigFace s_big[BIG_MAX];
+    __shared__ uint32_t s_nbig;
     const int tid = threadIdx.x;
+    if (tid == 0) s_nbig = 0u;  // (bin_window's barriers order this before the queueing below)
     const int64_t BF = (int64_t)B * F;
     const int64_t base = (int64_t)blockIdx.x * BIN_FACES;
     const int view = (int)(base / F);
@@ -167,6 +193,10 @@ k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const floa
         const int64_t idx = base + it * 256 + tid;
         const uint32_t tb = (uint32_t)(idx / F) * gx * gy;
         const uint32_t minx = rr[it].x & 0xffffu, miny = rr[it].x >> 16, maxx = rr[it].y & 0xffffu, maxy = rr[it].y >> 16;
+        if (touched[it] > BIG_RECT) {
+            const uint32_t q = atomicAdd(&s_nbig, 1u);
+            if (q < (uint32_t)BIG_MAX) { s_big[q] = BigFace{rr[it].x, rr[it].y, tb, 0u, 0u}; continue; }
+        }
         if (w.lds && mine[it] && touched[it] <= BIG_RECT) {
             for (uint32_t y = miny; y < maxy; y++)
                 for (uint32_t x = minx; x < maxx; x++) atomicAdd(&s_hist[(y - w.y0) * w.wx + (x - w.x0)], 1u);
@@ -181,6 +211,12 @@ k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const floa
             const uint32_t c = s_hist[y * w.wx + x];
             if (c) atomicAdd(&tile_count[(uint32_t)view * gx * gy + (uint32_t)(w.y0 + y) * gx + (uint32_t)(w.x0 + x)], c);
         }
+    const uint32_t nbig = min(s_nbig, (uint32_t)BIG_MAX);
+    for (uint32_t q = 0; q < nbig; q++) {
+        const BigFace f = s_big[q];
+        for (RectWalk t(f.rect_lo & 0xffffu, f.rect_lo >> 16, f.rect_hi & 0xffffu, f.rect_hi >> 16, (uint32_t)tid); t.valid(); t.next())
+            atomicAdd(&tile_count[f.tile_base + t.y * gx + t.x], 1u);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -189,7 +225,10 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face
                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys, uint32_t capacity) {
     __shared__ uint32_t s_hist[LDS_HIST_MAX];
     __shared__ int s_box[4];
+    __shared__ BigFace s_big[BIG_MAX];
+    __shared__ uint32_t s_nbig;
     const int tid = threadIdx.x;
+    if (tid == 0) s_nbig = 0u;
     const int64_t BF = (int64_t)B * F;
     const int64_t base = (int64_t)blockIdx.x * BIN_FACES;
     const int view = (int)(base / F);
@@ -232,6 +271,10 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face
         const uint32_t tb = (uint32_t)(idx / F) * gx * gy;
         const uint32_t minx = rr[it].x & 0xffffu, miny = rr[it].x >> 16, maxx = rr[it].y & 0xffffu, maxy = rr[it].y >> 16;
         const uint64_t key = ((uint64_t)__float_as_uint(key_depth[idx]) << 32) | (uint32_t)f;
+        if (touched[it] > BIG_RECT) {
+            const uint32_t q = atomicAdd(&s_nbig, 1u);
+            if (q < (uint32_t)BIG_MAX) { s_big[q] = BigFace{rr[it].x, rr[it].y, tb, (uint32_t)key, (uint32_t)(key >> 32)}; continue; }
+        }
         const bool direct = !(w.lds && mine[it]) || touched[it] > BIG_RECT;
         for (uint32_t y = miny; y < maxy; y++)
             for (uint32_t x = minx; x < maxx; x++) {
@@ -239,6 +282,25 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face
                                              : atomicAdd(&s_hist[(y - w.y0) * w.wx + (x - w.x0)], 1u);
                 if (slot < capacity) keys[slot] = key;
             }
+    }
+    __syncthreads();
+    const uint32_t nbig = min(s_nbig, (uint32_t)BIG_MAX);
+    for (uint32_t q = 0; q < nbig; q++) {
+        const BigFace f = s_big[q];
+        const uint64_t key = ((uint64_t)f.key_hi << 32) | f.key_lo;
+        // four returning atomics in flight per thread (one at a time: 0.28 ms for 64 screen-filling faces in one workgroup)
+        for (RectWalk t(f.rect_lo & 0xffffu, f.rect_lo >> 16, f.rect_hi & 0xffffu, f.rect_hi >> 16, (uint32_t)tid); t.valid();) {
+            uint32_t tile[4], slot[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                tile[u] = 0xffffffffu;
+                if (t.valid()) { tile[u] = f.tile_base + t.y * gx + t.x; t.next(); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) slot[u] = tile[u] != 0xffffffffu ? atomicAdd(&tile_cursor[tile[u]], 1u) : 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (slot[u] < capacity) keys[slot[u]] = key;
+        }
     }
 }
 
@@ -561,7 +623,7 @@ __device__ __forceinline__ void rank_quarter(const uint64_t* __restrict__ sk, ui
 
 __global__ void __launch_bounds__(256)
 k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_order,
-             uint64_t* __restrict__ keys, uint32_t* __restrict__ face_list) {
+             uint64_t* __restrict__ keys, uint32_t* __restrict__ face_list, uint32_t capacity) {
     __shared__ uint64_t s_keys[SORT_LDS_KEYS];
     __shared__ uint32_t s_rank[RANK_SORT_MAX];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -570,7 +632,8 @@ k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, const ui
     const uint32_t tile = tile_order[ti];  // longest first
     const uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
     const uint32_t n = end - begin;
-    if (n == 0) continue;
+    // (a segment beyond the buffer exists only while a size guess is being refuted: everything is redone then)
+    if (n == 0 || end > capacity) continue;
     __syncthreads();  // the previous tile's keys are no longer needed
     uint32_t npow2 = 1;
     while (npow2 < n) npow2 <<= 1;
@@ -682,10 +745,10 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
 }
 
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
-                       uint32_t* face_list, hipStream_t st) {
+                       uint32_t* face_list, uint32_t capacity, hipStream_t st) {
     if (ntiles == 0) return;
     StageScope t(DMR_STAGE_SORT, st);
-    k_sort_tiles<<<dim3((unsigned)std::min(ntiles, 256 * 64)), dim3(256), 0, st>>>((uint32_t)ntiles, tile_offset, tile_order, keys, face_list);
+    k_sort_tiles<<<dim3((unsigned)std::min(ntiles, 256 * 64)), dim3(256), 0, st>>>((uint32_t)ntiles, tile_offset, tile_order, keys, face_list, capacity);
 }
 
 }  // namespace dmr

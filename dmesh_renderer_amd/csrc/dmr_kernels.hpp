@@ -39,8 +39,10 @@ void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_of
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
                           const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
                           hipStream_t st);
+// capacity: entries the binning buffer holds; it is below R only while a size guess is being refuted (dmr_api.hip):
+// every kernel that walks the tile lists clamps to it, the results are then thrown away and redone
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
-                       uint32_t* face_list, hipStream_t st);
+                       uint32_t* face_list, uint32_t capacity, hipStream_t st);
 
 // ---- tri compositing (dmr_tri.hip)
 struct TriImageState {
@@ -54,7 +56,7 @@ struct TriImageState {
 // (A 32-byte record carrying face and vertex ids was tried: kernel 2 did not get faster, kernel 1 got 9 % slower.)
 struct alignas(16) HitRecord { uint32_t entry; uint32_t pixel; float T; float dL_dalpha; };
 void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
-                        const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
+                        const uint32_t* tile_offset, const uint32_t* face_list, uint32_t capacity, TriImageState img,
                         float* out_color, float* out_depth, hipStream_t st);
 // host_*: pinned host memory the kernel also writes its total to (no separate device->host copy)
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
@@ -85,7 +87,7 @@ size_t tet_colrec_bytes();
 void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st);
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
                                 const float* max_depth, const uint32_t* tile_offset, const uint32_t* face_list,
-                                TetImageState img, hipStream_t st);
+                                uint32_t capacity, TetImageState img, hipStream_t st);
 void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
                         float* out_color, float* out_depth, float* out_active, hipStream_t st);
 void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,

@@ -117,7 +117,7 @@ __device__ __forceinline__ float oriented_dot(const TetFaceRec& r, bool flip, V3
 
 __global__ void __launch_bounds__(256)
 k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const float* __restrict__ max_depth,
-                      const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ face_list) {
+                      const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ face_list, uint32_t capacity) {
     __shared__ HitRec s_rec[FI_CHUNK];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
@@ -130,7 +130,10 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
     if (inside) pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
 
     const int tile = (b * p.gy + ty) * p.gx + tx;
-    const uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
+    // (a list beyond the buffer -- only while a size guess is being refuted, the result is redone then -- holds no
+    // valid face ids: the tile is treated as empty)
+    uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
+    if (end > capacity) begin = end = 0u;
 
     bool done = !inside;
     float min_T = -1.0f, min_T_max_depth = -1.0f;
@@ -490,11 +493,11 @@ void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st) {
 
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
                                 const float* max_depth, const uint32_t* tile_offset, const uint32_t* face_list,
-                                TetImageState img, hipStream_t st) {
+                                uint32_t capacity, TetImageState img, hipStream_t st) {
     if (r1 <= r0) return;
     TetParams p = make_params(s, gx, gy, r0, img);
     StageScope t(DMR_STAGE_TET_FIRST, st);
-    k_tet_first_intersect<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, key_depth, max_depth, tile_offset, face_list);
+    k_tet_first_intersect<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, key_depth, max_depth, tile_offset, face_list, capacity);
 }
 
 void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,

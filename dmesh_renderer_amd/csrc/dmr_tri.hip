@@ -62,6 +62,7 @@ static_assert(sizeof(ShadeRec) == 112, "ShadeRec");
 
 struct TriParams {
     int B, P, F, W, H, gx, gy, r0, r1, dbg;
+    uint32_t list_capacity;  // entries face_list holds (< R only while a size guess is being refuted)
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* inv_mv; const float* inv_proj; const float* faces_intense; const float* bg;
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
@@ -200,7 +201,10 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     if (inside) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
     const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
 
-    const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
+    // A list that does not fit the binning buffer (only while a size guess is being refuted; everything is redone
+    // then) was neither completely scattered nor sorted: its entries are not face ids.  Such a tile renders as empty.
+    uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
+    if (end > p.list_capacity) begin = end = 0u;
 
     float T = 1.0f, pT = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last_contributor = 0, n_hits = 0, n_skipped = 0;
@@ -898,14 +902,16 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
     p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset; p.tile_order = img.tile_order;
+    p.list_capacity = 0xffffffffu;
     return p;
 }
 
 void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
-                        const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
+                        const uint32_t* tile_offset, const uint32_t* face_list, uint32_t capacity, TriImageState img,
                         float* out_color, float* out_depth, hipStream_t st) {
     if (r1 <= r0) return;
     TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
+    p.list_capacity = capacity;
     StageScope t(DMR_STAGE_TRI_FORWARD, st);
     k_tri_forward<FWD_CHUNK><<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, out_color, out_depth);
 }

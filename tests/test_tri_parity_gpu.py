@@ -148,6 +148,42 @@ def test_size_guess_is_refuted_and_redone(oracle, hip_device):
     assert rs[1] > 1.5 * rs[0], "second scene must exceed the size guess"
 
 
+def test_size_guess_refuted_by_screen_filling_faces(oracle, hip_device):
+    """Same view configuration, list-entries-per-face ratio up by 3x: a mesh, then the mesh plus screen-filling
+    triangles.  The guessed binning buffer is far too small; every kernel that walks the tile lists must stay
+    inside it until the stages are redone (this scenario once read and wrote past the buffer), and the
+    screen-filling faces go through the cooperative emission of the binning kernels."""
+    from dmesh_renderer_amd import _C
+    B, H, W = 1, 320, 320
+    gc, gd = upstream_grads(B, H, W)
+    base = scenes.layered_sheets(4, 24, B, H, W, seed=11)
+    big = scenes.layered_sheets(16, 2, B, H, W, seed=12, opacity=(0.01, 0.05))   # 32 triangles, one quad per layer
+    big["verts"] = big["verts"] * th.tensor([6.0, 6.0, 1.0])
+    P0 = base["verts"].shape[0]
+    both = dict(base)
+    both["verts"] = th.cat([base["verts"], big["verts"]]); both["verts_color"] = th.cat([base["verts_color"], big["verts_color"]])
+    both["faces"] = th.cat([base["faces"], big["faces"] + P0]); both["faces_opacity"] = th.cat([base["faces_opacity"], big["faces_opacity"]])
+    both["verts_depth"] = th.cat([base["verts_depth"], big["verts_depth"]], dim=1)
+    both["faces_intense"] = th.cat([base["faces_intense"], big["faces_intense"]], dim=1)
+    rs = []
+    for d in (base, both, base, both):
+        sc = oracle.scene_from_module_inputs(d, H, W)
+        ocolor, odepth, ost = oracle.tri_forward(sc)
+        og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+        args = c_args(d, hip_device)
+        out = _C.render_tris(*args, H, W)
+        g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7])
+        th.cuda.synchronize()
+        assert out[0] == ost.num_rendered
+        np.testing.assert_array_equal(_C.export("face_list", args, False, out[0], out[3:7], H, W, th.int32).cpu().numpy().view(np.uint32),
+                                      ost.get("values"))
+        assert np.abs(out[1].cpu().numpy() - ocolor).max() <= FWD_TOL
+        for got, key in zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")):
+            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, key
+        rs.append(out[0] / d["faces"].shape[0])
+    assert rs[1] > 2.0 * rs[0], "the second scene must refute the size guess by a wide margin"
+
+
 def test_module_autograd(oracle, hip_device):
     """TriRenderer Module: loss.backward() routes the five gradients like the reference wrapper."""
     import dmesh_renderer_amd as dmr
