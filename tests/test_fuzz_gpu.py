@@ -1,0 +1,121 @@
+"""Random triangle soups against the oracle: no lattice structure, vertices in front of, around and behind the
+camera (mirrored by clamp_w, Q2), slivers, repeated vertices and zero-area faces, sizes from sub-pixel to several
+screens, random opacities including 0 and 1.  Indices bit-exact, forward 1e-5, gradients 1e-4."""
+import numpy as np
+import pytest
+import torch as th
+
+from dmesh_renderer_amd import scenes
+from util import c_args, rel_err, upstream_grads
+
+pytestmark = pytest.mark.gpu
+NAMES = ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")
+
+
+def _soup(seed, P, F, B, H, W):
+    g = th.Generator().manual_seed(seed)
+    base = scenes.layered_sheets(1, 3, B, H, W, seed=seed)  # cameras, bg
+    spread = th.tensor([2.5, 2.5, 4.0])
+    verts = (th.rand(P, 3, generator=g) - 0.5) * 2.0 * spread
+    faces = th.randint(0, P, (F, 3), generator=g, dtype=th.int32)
+    # a tenth of the faces: small triangles around one vertex; a few degenerate ones
+    k = F // 10
+    centre = th.randint(0, P - 3, (k,), generator=g, dtype=th.int32)
+    faces[:k, 0] = centre; faces[:k, 1] = centre + 1; faces[:k, 2] = centre + 2
+    verts[1::7] = verts[0::7][: verts[1::7].shape[0]] + 0.01 * th.randn(verts[1::7].shape, generator=g)
+    faces[k:k + 5, 1] = faces[k:k + 5, 0]  # zero area
+    op = th.rand(F, generator=g)
+    op[::11] = 0.0
+    op[5::13] = 1.0
+    d = dict(base)
+    d["verts"] = verts.float(); d["faces"] = faces
+    d["verts_color"] = th.rand(P, 3, generator=g); d["faces_opacity"] = op
+    d["verts_depth"] = th.randn(B, P, generator=g); d["faces_intense"] = th.rand(B, F, generator=g) + 0.5
+    return d
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_triangle_soup(oracle, hip_device, seed):
+    from dmesh_renderer_amd import _C
+    B, H, W = 2, 136, 200
+    d = _soup(seed, 240, 700, B, H, W)
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    ocolor, odepth, ost = oracle.tri_forward(sc)
+    args = c_args(d, hip_device)
+    out = _C.render_tris(*args, H, W)
+    th.cuda.synchronize()
+    R, bufs = out[0], out[3:7]
+    assert R == ost.num_rendered
+    ex = lambda n, dt: _C.export(n, args, False, R, bufs, H, W, dt).cpu().numpy()
+    np.testing.assert_array_equal(ex("tiles_touched", th.int32).view(np.uint32), ost.get("tiles_touched"))
+    np.testing.assert_array_equal(ex("ranges", th.int32).view(np.uint32), ost.get("ranges"))
+    np.testing.assert_array_equal(ex("face_list", th.int32).view(np.uint32), ost.get("values"))
+    np.testing.assert_array_equal(ex("n_contrib", th.int32).view(np.uint32), ost.get("n_contrib"))
+    ok = np.isfinite(ocolor).all(axis=1, keepdims=True)
+    assert np.abs(np.where(ok, out[1].cpu().numpy() - ocolor, 0.0)).max() <= 1e-5
+    gc, gd = upstream_grads(B, H, W)
+    og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+    g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), R, *bufs)
+    th.cuda.synchronize()
+    for got, k in zip(g, NAMES):
+        a, r = got.cpu().numpy(), og[k]
+        fin = np.isfinite(r)
+        assert np.array_equal(np.isfinite(a), fin) or k == "verts", k   # non-finite entries (Q12) sit in the same places
+        assert rel_err(np.where(fin, a, 0.0), np.where(fin, r, 0.0)) <= 1e-4, k
+
+
+def _delaunay(seed, npts, B, H, W):
+    """Delaunay tetrahedralisation of random points (scipy): irregular tets, slivers included."""
+    from scipy.spatial import Delaunay
+    rng = np.random.RandomState(seed)
+    pts = rng.uniform(-1.0, 1.0, (npts, 3))
+    tets = Delaunay(pts).simplices.astype(np.int64)
+    T = tets.shape[0]
+    tri_idx = np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]])
+    tri = np.sort(tets[:, tri_idx].reshape(-1, 3), axis=1)
+    key = (tri[:, 0] * (npts + 1) + tri[:, 1]) * (npts + 1) + tri[:, 2]
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    F = uniq.shape[0]
+    faces = tri[first].astype(np.int32)
+    tet_faces = inv.reshape(T, 4).astype(np.int32)
+    face_tets = np.full((F, 2), -1, dtype=np.int32)
+    owner = np.repeat(np.arange(T), 4)
+    srt = np.argsort(inv, kind="stable")
+    inv_s, own_s = inv[srt], owner[srt]
+    start = np.searchsorted(inv_s, np.arange(F), side="left")
+    cnt = np.searchsorted(inv_s, np.arange(F), side="right") - start
+    face_tets[:, 0] = own_s[start]
+    face_tets[cnt > 1, 1] = own_s[start[cnt > 1] + 1]
+    base = scenes.kuhn_tets(2, B, H, W, seed=seed)  # cameras, bg
+    g = th.Generator().manual_seed(seed)
+    d = dict(base)
+    d["verts"] = th.from_numpy(pts).float(); d["faces"] = th.from_numpy(faces); d["tets"] = th.from_numpy(tets.astype(np.int32))
+    d["face_tets"] = th.from_numpy(face_tets); d["tet_faces"] = th.from_numpy(tet_faces)
+    d["verts_color"] = th.rand(npts, 3, generator=g); d["faces_opacity"] = th.rand(F, generator=g) * 0.4 + 0.02
+    d["faces_intense"] = th.rand(B, F, generator=g) * 0.5 + 0.5
+    d["verts_depth"] = th.randn(B, npts, generator=g)
+    return d
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_delaunay_tets(oracle, hip_device, seed):
+    from dmesh_renderer_amd import _C
+    B, H, W = 2, 120, 168
+    d = _delaunay(seed, 400, B, H, W)
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    ocolor, odepth, oactive, ost = oracle.tet_forward(sc)
+    args = c_args(d, hip_device, tet=True)
+    out = _C.render_tets(*args, H, W, 0)
+    th.cuda.synchronize()
+    ex = lambda n, dt: _C.export(n, args, True, 0, out[3:7], H, W, dt).cpu().numpy()
+    np.testing.assert_array_equal(ex("first_face", th.int32), ost.get("first_face"))
+    np.testing.assert_array_equal(ex("first_tet", th.int32), ost.get("first_tet"))
+    np.testing.assert_array_equal(ex("last_face", th.int32), ost.get("last_face"))
+    np.testing.assert_array_equal(out[2].cpu().numpy(), oactive)
+    assert np.abs(out[0].cpu().numpy() - ocolor).max() <= 1e-5
+    assert np.abs(out[1].cpu().numpy() - odepth).max() <= 1e-5
+    gc, gd = upstream_grads(B, H, W)
+    og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+    g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *out[3:7])
+    for got, k in zip(g, ("verts_color", "faces_opacity")):
+        assert rel_err(got.cpu().numpy(), og[k]) <= 1e-4, k
