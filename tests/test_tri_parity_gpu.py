@@ -26,6 +26,9 @@ CASES = {
     "very_dense": (40, 9, 1, 32, 32, (0.01, 0.08)),
     # 2 x 96 x 96 = 18 432 tiles: the multi-workgroup tile scans (more than 16 384 tiles) and windowed binning
     "many_tiles": (3, 24, 2, 1536, 1536, (0.1, 0.5)),
+    # 300 consecutive screen-filling triangles (400 tiles each): more than the binning kernels' LDS queue of big
+    # faces holds per workgroup (128), so both the cooperative emission and its per-thread fallback run
+    "many_big": (150, 2, 1, 320, 320, (0.005, 0.02)),
     # triangles far larger than the image, vertices far off-screen and behind the camera (mirrored by
     # clamp_w, Q2): exercises whole-tile coverage, the non-"near" / 32-bit coverage paths and int32 wrap (Q7)
     "huge": (3, 4, 2, 96, 144, (0.1, 0.4)),
@@ -37,6 +40,8 @@ def _make(case):
     d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
     if case == "huge":
         d["verts"] = d["verts"] * th.tensor([40.0, 40.0, 3.0])
+    if case == "many_big":
+        d["verts"] = d["verts"] * th.tensor([6.0, 6.0, 1.0])
     if case == "alpha_one":
         d["faces_opacity"][::5] = 1.0
     return d, B, H, W
