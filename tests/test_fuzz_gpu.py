@@ -119,3 +119,31 @@ def test_delaunay_tets(oracle, hip_device, seed):
     g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *out[3:7])
     for got, k in zip(g, ("verts_color", "faces_opacity")):
         assert rel_err(got.cpu().numpy(), og[k]) <= 1e-4, k
+
+
+def test_changing_shapes_and_streams(oracle, hip_device):
+    """A training-loop pattern: the face count changes every call (the size guess is a ratio, never exact), calls
+    alternate between PyTorch's default stream and a side stream, two meshes are in flight.  Every result is checked."""
+    from dmesh_renderer_amd import _C
+    B, H, W = 1, 160, 160
+    gc, gd = upstream_grads(B, H, W)
+    side = th.cuda.Stream(device=hip_device)
+    rng = np.random.RandomState(0)
+    for it in range(24):
+        L, n = int(rng.randint(1, 6)), int(rng.randint(4, 20))
+        d = scenes.layered_sheets(L, n, B, H, W, seed=it)
+        if it % 5 == 4:
+            d["verts"] = d["verts"] * float(rng.uniform(0.2, 3.0))
+        args = c_args(d, hip_device)
+        ctx = th.cuda.stream(side) if it % 2 else th.cuda.stream(th.cuda.current_stream(hip_device))
+        with ctx:
+            out = _C.render_tris(*args, H, W)
+            g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7])
+        th.cuda.synchronize()
+        sc = oracle.scene_from_module_inputs(d, H, W)
+        ocolor, odepth, ost = oracle.tri_forward(sc)
+        og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+        assert out[0] == ost.num_rendered, it
+        assert np.abs(out[1].cpu().numpy() - ocolor).max() <= 1e-5, it
+        for got, k in zip(g, NAMES):
+            assert rel_err(got.cpu().numpy(), og[k]) <= 1e-4, (it, k)
