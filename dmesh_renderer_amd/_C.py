@@ -150,6 +150,23 @@ class _Call:
         return C.c_void_p(th.cuda.current_stream(self.dev).cuda_stream)
 
 
+class _on_device:
+    """`with th.cuda.device(dev)` when dev is not already the current device (the context manager costs ~10 us of a
+    small step; the common case is one device per process)."""
+
+    def __init__(self, dev):
+        self.ctx = None if th.cuda.current_device() == dev.index else th.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def _ptr(t: th.Tensor):
     return t.data_ptr() if t.numel() else None
 
@@ -165,7 +182,7 @@ def render_tris(background, verts, faces, verts_color, faces_opacity, mv_mats, p
     _check_common(verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats, inv_proj_mats,
                   verts_depth, faces_intense, tet=False)
     dev = _device_of(verts)
-    with th.cuda.device(dev):
+    with _on_device(dev):
         call = _Call(dev, background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                      inv_proj_mats, verts_depth, faces_intense, image_height, image_width, rows=rows)
         # the kernels write every pixel of the rendered rows; zero-fill (render.cu:88-89) is only needed when
@@ -190,7 +207,7 @@ def render_tris_backward(background, verts, faces, verts_color, faces_opacity, m
     lib = _lib.load()
     dev = _device_of(verts)
     H, W = dL_dout_color.size(2), dL_dout_color.size(3)  # render.cu:163-164
-    with th.cuda.device(dev):
+    with _on_device(dev):
         call = _Call(dev, background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                      inv_proj_mats, verts_depth, faces_intense, H, W, rows=rows)
         gc = _f32(dL_dout_color, "dL_dout_color")  # may arrive non-contiguous / expanded (render.cu:197-198)
@@ -229,7 +246,7 @@ def render_tets(background, verts, faces, verts_color, faces_opacity, mv_mats, p
                   verts_depth, faces_intense, tet=True)
     _check_tets(faces, tets, face_tets, tet_faces)
     dev = _device_of(verts)
-    with th.cuda.device(dev):
+    with _on_device(dev):
         call = _Call(dev, background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                      inv_proj_mats, verts_depth, faces_intense, image_height, image_width,
                      tets=tets, face_tets=face_tets, tet_faces=tet_faces, seed=ray_random_seed, rows=rows)
@@ -256,7 +273,7 @@ def render_tets_backward(background, verts, faces, verts_color, faces_opacity, m
     lib = _lib.load()
     dev = _device_of(verts)
     H, W = grad_color.size(2), grad_color.size(3)  # render.cu:371-372
-    with th.cuda.device(dev):
+    with _on_device(dev):
         call = _Call(dev, background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                      inv_proj_mats, verts_depth, faces_intense, H, W,
                      tets=tets, face_tets=face_tets, tet_faces=tet_faces, seed=0, rows=rows)
@@ -272,31 +289,23 @@ def render_tets_backward(background, verts, faces, verts_color, faces_opacity, m
 
 
 def invert_mats(*mats: th.Tensor):
-    """th.inverse of [B,4,4] float32 HIP tensors with ONE library kernel for all of them (dmr_invert_mats: adjugate in
+    """th.inverse of [B,4,4] float32 HIP tensors with one small library kernel each (dmr_invert_mats: adjugate in
     double precision).  Extension over the reference's `_C` (its wrapper calls th.inverse twice per forward,
     dmesh_renderer/__init__.py:62-63: two batched LU factorisations, ~0.12 ms of small kernels on the GPU).
     Returns contiguous tensors."""
     lib = _lib.load()
     dev = _device_of(mats[0])
-    prepared = []
-    for m in mats:
-        if m.dim() != 3 or m.size(1) != 4 or m.size(2) != 4:
-            _err("matrices must have dimensions (B, 4, 4)")
-        prepared.append(_mat(m, "matrix"))
-    out = th.empty((sum(m.size(0) for m in mats), 4, 4), dtype=th.float32, device=dev)
-    with th.cuda.device(dev):
+    res = []
+    with _on_device(dev):
         stream = C.c_void_p(th.cuda.current_stream(dev).cuda_stream)
-        off = 0
-        # consecutive matrices of one layout could share a launch; two launches of one tiny kernel are cheap enough
-        for (t, flag) in prepared:
-            n = t.size(0)
-            if n and lib.dmr_invert_mats(t.data_ptr(), n, flag, out[off:].data_ptr(), stream):
+        for m in mats:
+            if m.dim() != 3 or m.size(1) != 4 or m.size(2) != 4:
+                _err("matrices must have dimensions (B, 4, 4)")
+            t, flag = _mat(m, "matrix")
+            out = th.empty((t.size(0), 4, 4), dtype=th.float32, device=dev)
+            if t.size(0) and lib.dmr_invert_mats(t.data_ptr(), t.size(0), flag, out.data_ptr(), stream):
                 _raise_lib()
-            off += n
-    res, off = [], 0
-    for m in mats:
-        res.append(out[off:off + m.size(0)])
-        off += m.size(0)
+            res.append(out)
     return tuple(res)
 
 
@@ -306,7 +315,7 @@ def export(name: str, call_args: Tuple, is_tet: bool, num_rendered: int, buffers
     (dmr_export).  `call_args` are the 11 (tri) / 14 (tet) leading tensors of render_*."""
     lib = _lib.load()
     dev = call_args[1].device
-    with th.cuda.device(dev):
+    with _on_device(dev):
         tet_kw = dict(tets=call_args[11], face_tets=call_args[12], tet_faces=call_args[13]) if is_tet else {}
         call = _Call(dev, *call_args[:11], H, W, **tet_kw)
         bufs = [_ptr(b) for b in buffers]
