@@ -197,3 +197,38 @@ def test_c5_matches_oracle(hip_device, oracle):
     og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
     for got, k in zip(g, NAMES):
         assert rel_err(got.cpu().numpy(), og[k]) <= GRAD_TOL, k
+
+
+def test_four_views_1080p(hip_device, oracle):
+    """B = 4 views at 1920 x 1080 (32 640 tiles: the multi-workgroup scans, binning windows per view, per-view depth /
+    intensity gradients) against the oracle, and as two tile-row bands."""
+    from dmesh_renderer_amd import _C
+    B, H, W = 4, 1080, 1920
+    d = scenes.layered_sheets(6, 48, B, H, W, seed=4)
+    args = c_args(d, hip_device)
+    gc, gd = upstream_grads(B, H, W)
+    out = _C.render_tris(*args, H, W)
+    g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7])
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    ocolor, odepth, ost = oracle.tri_forward(sc)
+    assert out[0] == ost.num_rendered
+    np.testing.assert_array_equal(_C.export("ranges", args, False, out[0], out[3:7], H, W, th.int32).cpu().numpy().view(np.uint32),
+                                  ost.get("ranges"))
+    np.testing.assert_array_equal(_C.export("face_list", args, False, out[0], out[3:7], H, W, th.int32).cpu().numpy().view(np.uint32),
+                                  ost.get("values"))
+    assert np.abs(out[1].cpu().numpy() - ocolor).max() <= FWD_TOL
+    assert np.abs(out[2].cpu().numpy() - odepth).max() <= FWD_TOL
+    og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+    for got, k in zip(g, NAMES):
+        assert rel_err(got.cpu().numpy(), og[k]) <= GRAD_TOL, k
+    gy = (H + 15) // 16
+    gsum = [th.zeros_like(t) for t in g]
+    color = th.zeros_like(out[1])
+    for rows in ((0, 30), (30, gy)):
+        o = _C.render_tris(*args, H, W, rows=rows)
+        color += o[1]
+        for a, b in zip(gsum, _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), o[0], *o[3:7], rows=rows)):
+            a += b
+    assert th.equal(color, out[1])
+    for a, b, k in zip(gsum, g, NAMES):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, k
