@@ -95,10 +95,12 @@ def main():
 
     def step():
         o = _C.render_tris(*args, H, W, rows=rows)
-        g = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7], rows=rows)
         if world > 1:
-            th.cat([t.reshape(-1) for t in g], out=flat)
-            dist.all_reduce(flat)  # ONE collective over the flattened gradient buffer
+            # the five gradients land back to back in `flat` (views are returned): ONE collective, no concatenation
+            g = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7], rows=rows, flat_out=flat)
+            dist.all_reduce(flat)
+        else:
+            g = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7])
         return o, g
 
     lib = _lib.load()

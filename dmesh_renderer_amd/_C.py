@@ -202,8 +202,12 @@ def render_tris(background, verts, faces, verts_color, faces_opacity, mv_mats, p
 
 def render_tris_backward(background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                          inv_proj_mats, verts_depth, faces_intense, dL_dout_color, dL_dout_depth, R,
-                         pointBuffer, faceBuffer, binningBuffer, imageBuffer, rows=(0, 0)):
-    """-> (dL_dverts [P,3], dL_dvcolor [P,3], dL_dfopacity [F], dL_dvdepth [B,P], dL_dfintense [B,F])"""
+                         pointBuffer, faceBuffer, binningBuffer, imageBuffer, rows=(0, 0), flat_out=None):
+    """-> (dL_dverts [P,3], dL_dvcolor [P,3], dL_dfopacity [F], dL_dvdepth [B,P], dL_dfintense [B,F])
+
+    Extension for the sharded path: `flat_out`, a float32 HIP tensor of 6P + F + B(P + F) elements, receives the five
+    gradients back to back ([3P | 3P | F | BP | BF], the layout of the one all-reduce in sharding.py) and the
+    returned tensors are views into it -- no concatenation kernel before the collective."""
     lib = _lib.load()
     dev = _device_of(verts)
     H, W = dL_dout_color.size(2), dL_dout_color.size(3)  # render.cu:163-164
@@ -213,11 +217,20 @@ def render_tris_backward(background, verts, faces, verts_color, faces_opacity, m
         gc = _f32(dL_dout_color, "dL_dout_color")  # may arrive non-contiguous / expanded (render.cu:197-198)
         gd = _f32(dL_dout_depth, "dL_dout_depth")
         B, P, F = call.B, call.P, call.F
-        g_verts = th.empty((P, 3), dtype=th.float32, device=dev)
-        g_vcolor = th.empty((P, NUM_CHANNELS), dtype=th.float32, device=dev)
-        g_fop = th.empty((F,), dtype=th.float32, device=dev)
-        g_vdepth = th.empty((B, P), dtype=th.float32, device=dev)
-        g_fint = th.empty((B, F), dtype=th.float32, device=dev)
+        if flat_out is None:
+            g_verts = th.empty((P, 3), dtype=th.float32, device=dev)
+            g_vcolor = th.empty((P, NUM_CHANNELS), dtype=th.float32, device=dev)
+            g_fop = th.empty((F,), dtype=th.float32, device=dev)
+            g_vdepth = th.empty((B, P), dtype=th.float32, device=dev)
+            g_fint = th.empty((B, F), dtype=th.float32, device=dev)
+        else:
+            sizes = (3 * P, 3 * P, F, B * P, B * F)
+            if flat_out.dtype != th.float32 or flat_out.device != dev or not flat_out.is_contiguous() \
+                    or flat_out.numel() != sum(sizes):
+                _err(f"flat_out must be a contiguous float32 tensor of {sum(sizes)} elements on {dev}")
+            parts = th.split(flat_out.view(-1), sizes)
+            g_verts, g_vcolor, g_fop = parts[0].view(P, 3), parts[1].view(P, NUM_CHANNELS), parts[2]
+            g_vdepth, g_fint = parts[3].view(B, P), parts[4].view(B, F)
         bufs = [b.contiguous() for b in (pointBuffer, faceBuffer, binningBuffer, imageBuffer)]
         rc = lib.dmr_tri_backward(C.byref(call.scene), _ptr(gc), _ptr(gd), int(R), *[_ptr(b) for b in bufs],
                                   _ptr(g_verts), _ptr(g_vcolor), _ptr(g_fop), _ptr(g_vdepth), _ptr(g_fint),

@@ -127,6 +127,27 @@ def test_band_rows_compose(oracle, hip_device):
         assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) <= GRAD_TOL
 
 
+def test_flat_gradient_output(hip_device):
+    """flat_out: the five gradients written back to back into one caller-owned buffer (the all-reduce payload)."""
+    from dmesh_renderer_amd import _C
+    L, n, B, H, W, op = CASES["ragged"]
+    d = scenes.layered_sheets(L, n, B, H, W, seed=5, opacity=op)
+    args = c_args(d, hip_device)
+    gc, gd = upstream_grads(B, H, W)
+    gc, gd = gc.to(hip_device), gd.to(hip_device)
+    o = _C.render_tris(*args, H, W)
+    g = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7])
+    P, F = d["verts"].shape[0], d["faces"].shape[0]
+    flat = th.full((6 * P + F + B * (P + F),), float("nan"), device=hip_device)
+    gv = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7], flat_out=flat)
+    assert all(v.data_ptr() >= flat.data_ptr() for v in gv) and not th.isnan(flat).any()
+    for a, b_ in zip(gv, g):
+        assert a.shape == b_.shape and rel_err(a.cpu().numpy(), b_.cpu().numpy()) <= 1e-5
+    assert rel_err(flat.cpu().numpy(), th.cat([t.reshape(-1) for t in g]).cpu().numpy()) <= 1e-5
+    with pytest.raises(RuntimeError, match="flat_out"):
+        _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7], flat_out=flat[:-1])
+
+
 def test_size_guess_is_refuted_and_redone(oracle, hip_device):
     """Speculative sizing: the library sizes the binning / hit-record buffers from the previous call with the
     same tensor shapes.  Render a small-on-screen mesh first, then the same shapes filling the screen (R and the
