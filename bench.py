@@ -94,7 +94,7 @@ def main():
     flat = th.empty(sum(sizes), dtype=th.float32, device=dev)
 
     def step():
-        o = _C.render_tris(*args, H, W, rows=rows)
+        o = _C.render_tris(*args, H, W, rows=rows, fill_outside=False)  # a rank only owns the rows of its band
         if world > 1:
             # the five gradients land back to back in `flat` (views are returned): ONE collective, no concatenation
             g = _C.render_tris_backward(*args, gc, gd, o[0], *o[3:7], rows=rows, flat_out=flat)

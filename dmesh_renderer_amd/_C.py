@@ -176,8 +176,11 @@ def _raise_lib():
 
 
 def render_tris(background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
-                inv_proj_mats, verts_depth, faces_intense, image_height, image_width, rows=(0, 0)):
-    """-> (num_rendered:int, color [B,3,H,W], depth [B,1,H,W], pointBuffer, faceBuffer, binningBuffer, imgBuffer)"""
+                inv_proj_mats, verts_depth, faces_intense, image_height, image_width, rows=(0, 0), fill_outside=True):
+    """-> (num_rendered:int, color [B,3,H,W], depth [B,1,H,W], pointBuffer, faceBuffer, binningBuffer, imgBuffer)
+
+    Extensions for the sharded path: `rows=(begin, end)` renders a band of 16-pixel tile rows; pixels outside it are
+    zero, or left uninitialised with `fill_outside=False` (a rank that only ever reads its own rows saves the fill)."""
     lib = _lib.load()
     _check_common(verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats, inv_proj_mats,
                   verts_depth, faces_intense, tet=False)
@@ -187,7 +190,7 @@ def render_tris(background, verts, faces, verts_color, faces_opacity, mv_mats, p
                      inv_proj_mats, verts_depth, faces_intense, image_height, image_width, rows=rows)
         # the kernels write every pixel of the rendered rows; zero-fill (render.cu:88-89) is only needed when
         # nothing is launched (P == 0 / F == 0, render.cu:105) or when a band leaves rows untouched
-        full = tuple(rows) == (0, 0) and call.P > 0 and call.F > 0
+        full = (tuple(rows) == (0, 0) or not fill_outside) and call.P > 0 and call.F > 0
         alloc_img = th.empty if full else th.zeros
         color = alloc_img((call.B, NUM_CHANNELS, call.H, call.W), dtype=th.float32, device=dev)
         depth = alloc_img((call.B, 1, call.H, call.W), dtype=th.float32, device=dev)
