@@ -198,42 +198,40 @@ template <bool FWD>
 __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet,
                                            float& curr_rt, float& curr_iu, float& curr_iv) {
     const int4 tr = p.tetrec[curr_tet];
-    const int e[4] = {tr.x, tr.y, tr.z, tr.w};
-    int others[3] = {0, 0, 0};
-    bool oflip[3] = {false, false, false};
-    int cnt = 0;
-    bool cur_flip = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int tf = e[i] & 0x7fffffff;
-        if (tf == curr_face) { cur_flip = e[i] < 0; continue; }
-        if (cnt < 3) { others[cnt] = tf; oflip[cnt] = e[i] < 0; }
-        cnt++;
-    }
-    if (cnt != 3) return false;
+    // The three faces of the tet other than the current one, in the record's order, with their orientation bits --
+    // by selects, not by indexing small arrays (which the compiler put in scratch memory: 12 scratch accesses per step).
+    const int t0 = tr.x & 0x7fffffff, t1 = tr.y & 0x7fffffff, t2 = tr.z & 0x7fffffff, t3 = tr.w & 0x7fffffff;
+    const bool m0 = t0 == curr_face, m1 = t1 == curr_face, m2 = t2 == curr_face, m3 = t3 == curr_face;
+    if ((int)m0 + (int)m1 + (int)m2 + (int)m3 != 1) return false;  // the reference's `cnt != 3`
+    const bool s1 = m0, s2 = m0 || m1, s3 = s2 || m2;  // entry i of `others` is record entry i + (shift i)
+    const int r0e = s1 ? tr.y : tr.x, r1e = s2 ? tr.z : tr.y, r2e = s3 ? tr.w : tr.z;
+    const int others0 = r0e & 0x7fffffff, others1 = r1e & 0x7fffffff, others2 = r2e & 0x7fffffff;
+    const bool oflip0 = r0e < 0, oflip1 = r1e < 0, oflip2 = r2e < 0;
+    const bool cur_flip = (m0 ? tr.x : (m1 ? tr.y : (m2 ? tr.z : tr.w))) < 0;
     // the three candidate faces: independent 64-byte records, all in flight together
     // (a face id outside [0, F) -- malformed tet_faces -- never hits instead of reading out of bounds)
-    const bool oval[3] = {(unsigned)others[0] < (unsigned)p.F, (unsigned)others[1] < (unsigned)p.F, (unsigned)others[2] < (unsigned)p.F};
-    const TetFaceRec r0 = load_facerec(p.facerec, oval[0] ? others[0] : 0);
-    const TetFaceRec r1 = load_facerec(p.facerec, oval[1] ? others[1] : 0);
-    const TetFaceRec r2 = load_facerec(p.facerec, oval[2] ? others[2] : 0);
+    const bool oval0 = (unsigned)others0 < (unsigned)p.F, oval1 = (unsigned)others1 < (unsigned)p.F, oval2 = (unsigned)others2 < (unsigned)p.F;
+    const TetFaceRec r0 = load_facerec(p.facerec, oval0 ? others0 : 0);
+    const TetFaceRec r1 = load_facerec(p.facerec, oval1 ? others1 : 0);
+    const TetFaceRec r2 = load_facerec(p.facerec, oval2 ? others2 : 0);
     const TetFaceRec rc = load_facerec(p.facerec, curr_face);
     bool ok = true;
     const float dcur = oriented_dot(rc, cur_flip, rd);
     if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
     int nf = -1, ncnt = 0, nft0 = -1, nft1 = -1;
     float nrt = 0, niu = 0, niv = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const TetFaceRec& r = i == 0 ? r0 : (i == 1 ? r1 : r2);
+    auto test = [&](const TetFaceRec& r, int of, bool flip, bool val) {
         V3 tuv;
         const bool hit = ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
-                                     {r.p2[0], r.p2[1], r.p2[2]}, tuv) && oval[i];
-        const float dn = oriented_dot(r, oflip[i], rd);
+                                     {r.p2[0], r.p2[1], r.p2[2]}, tuv) && val;
+        const float dn = oriented_dot(r, flip, rd);
         if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) {
-            nf = others[i]; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; ncnt++;
+            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; ncnt++;
         }
-    }
+    };
+    test(r0, others0, oflip0, oval0);
+    test(r1, others1, oflip1, oval1);
+    test(r2, others2, oflip2, oval2);
     if (ncnt != 1 || !ok) return false;
     int nt = -1;
     if (!(nft0 == curr_tet || nft0 == -1)) nt = nft0;
