@@ -184,11 +184,13 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
     p.img.first_tet[bpix] = ft;
 }
 
-__device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int face, float& rt, float& iu, float& iv) {
+// (t, u, v) of the ray on `face` and the face's unit normal (carried from step to step by the march)
+__device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int face, float& rt, float& iu, float& iv, V3& n) {
     V3 tuv = {0, 0, 0};
     const TetFaceRec r = load_facerec(p.facerec, face);
     ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]}, {r.p2[0], r.p2[1], r.p2[2]}, tuv);
     rt = tuv.x; iu = tuv.y; iv = tuv.z;
+    n = {r.n[0], r.n[1], r.n[2]};
 }
 
 // One march step shared by forward (FWD: leave through the face whose outward normal follows
@@ -196,7 +198,7 @@ __device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int f
 // must stop ("error cases" 1-3 of the reference).
 template <bool FWD>
 __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet,
-                                           float& curr_rt, float& curr_iu, float& curr_iv) {
+                                           float& curr_rt, float& curr_iu, float& curr_iv, V3& curr_n) {
     const int4 tr = p.tetrec[curr_tet];
     // The three faces of the tet other than the current one, in the record's order, with their orientation bits --
     // by selects, not by indexing small arrays (which the compiler put in scratch memory: 12 scratch accesses per step).
@@ -214,19 +216,20 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     const TetFaceRec r0 = load_facerec(p.facerec, oval0 ? others0 : 0);
     const TetFaceRec r1 = load_facerec(p.facerec, oval1 ? others1 : 0);
     const TetFaceRec r2 = load_facerec(p.facerec, oval2 ? others2 : 0);
-    const TetFaceRec rc = load_facerec(p.facerec, curr_face);
     bool ok = true;
-    const float dcur = oriented_dot(rc, cur_flip, rd);
+    const float dcur0 = dot(curr_n, rd);  // the current face's unit normal came with the previous step
+    const float dcur = cur_flip ? -dcur0 : dcur0;
     if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
     int nf = -1, ncnt = 0, nft0 = -1, nft1 = -1;
     float nrt = 0, niu = 0, niv = 0;
+    V3 nn = {0, 0, 0};
     auto test = [&](const TetFaceRec& r, int of, bool flip, bool val) {
         V3 tuv;
         const bool hit = ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
                                      {r.p2[0], r.p2[1], r.p2[2]}, tuv) && val;
         const float dn = oriented_dot(r, flip, rd);
         if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) {
-            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; ncnt++;
+            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; nn = {r.n[0], r.n[1], r.n[2]}; ncnt++;
         }
     };
     test(r0, others0, oflip0, oval0);
@@ -236,7 +239,7 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     int nt = -1;
     if (!(nft0 == curr_tet || nft0 == -1)) nt = nft0;
     else if (!(nft1 == curr_tet || nft1 == -1)) nt = nft1;
-    curr_face = nf; curr_tet = nt; curr_rt = nrt; curr_iu = niu; curr_iv = niv;
+    curr_face = nf; curr_tet = nt; curr_rt = nrt; curr_iu = niu; curr_iv = niv; curr_n = nn;
     return true;
 }
 
@@ -256,8 +259,9 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     bool done = false;
     int curr_face = first_face, curr_tet = first_tet;
     float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
+    V3 curr_n = {0, 0, 0};
     if (first_face == -1 || first_tet == -1) done = true;
-    else face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv);
+    else face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv, curr_n);
 
     V3 C = {0, 0, 0};
     float D = 0.f, log_T = 0.f, prev_log_T = 0.f;
@@ -286,7 +290,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         last_face = curr_face;
         last_tet = curr_tet;
         if (curr_tet == -1) { active = true; done = true; }
-        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv)) done = true;
+        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
     }
     p.img.final_log_T[bpix] = log_T;
     p.img.final_prev_log_T[bpix] = prev_log_T;
@@ -376,7 +380,8 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
 
         int curr_face = last_face, curr_tet = p.img.last_tet[bpix];
         float curr_rt, curr_iu, curr_iv;
-        face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv);
+        V3 curr_n;
+        face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv, curr_n);
         // step back across the last face (backward.cu:223-232)
         for (int i = 0; i < 2; i++) {
             const int t = p.face_tets[2 * curr_face + i];
@@ -443,7 +448,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
             if (curr_face == first_face) done = true;
             if (!done) {
                 if (curr_tet == -1) done = true;
-                else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv)) done = true;
+                else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
             }
         }
     }
