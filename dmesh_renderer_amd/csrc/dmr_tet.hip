@@ -427,12 +427,31 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
                 dop += (-final_T / (1.f - opacity)) * bg_dot;
                 dop += (-final_T / (1.f - opacity)) * bd_dot;
             }
-            const float g[10] = {i0 * dc0 * intense, i0 * dc1 * intense, i0 * dc2 * intense,
-                                 i1 * dc0 * intense, i1 * dc1 * intense, i1 * dc2 * intense,
-                                 i2 * dc0 * intense, i2 * dc1 * intense, i2 * dc2 * intense, dop};
+            float g[10] = {i0 * dc0 * intense, i0 * dc1 * intense, i0 * dc2 * intense,
+                           i1 * dc0 * intense, i1 * dc1 * intense, i1 * dc2 * intense,
+                           i2 * dc0 * intense, i2 * dc1 * intense, i2 * dc2 * intense, dop};
+            // Neighbouring pixels march through the same faces in near lockstep, so the lanes of a wave pile onto a few
+            // table cells (same-address LDS atomics serialise: 0.13 of this kernel's 0.52 ms at C3).  When the four
+            // lanes of a DPP quad (four pixels in a row) hold the same face in this step, they add their values with
+            // two quad_perm exchanges and one lane goes to the table.  Lanes outside the loop read as "no face".
+            const int k1 = __builtin_amdgcn_update_dpp(-1, curr_face, 0xB1, 0xF, 0xF, false);  // lane ^ 1
+            const int k2 = __builtin_amdgcn_update_dpp(-1, curr_face, 0x4E, 0xF, 0xF, false);  // lane ^ 2
+            const int k3 = __builtin_amdgcn_update_dpp(-1, k1, 0x4E, 0xF, 0xF, false);         // lane ^ 3
+            const bool quad = k1 == curr_face && k2 == curr_face && k3 == curr_face;
+            if (quad) {
+#pragma unroll
+                for (int c = 0; c < 10; c++) {
+                    float t = g[c];
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, false));
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, false));
+                    g[c] = t;
+                }
+            }
             // (DMR_ABLATE bit 2048, tests only: odd faces are refused a slot, which exercises the direct-atomic fallback)
-            const int slot = ((p.dbg & 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face);
-            if (slot >= 0) {
+            const int slot = (quad && (lane & 3)) ? -2 : (((p.dbg & 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face));
+            if (slot == -2) {
+                // this lane's values went out with lane (lane & ~3) of its quad
+            } else if (slot >= 0) {
 #pragma unroll
                 for (int c = 0; c < 10; c++) atomicAdd(&s_val[c][slot], (double)g[c]);
             } else {
@@ -442,7 +461,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
                     atomicAdd(&dL_dvcolor[3 * v1 + c], g[3 + c]);
                     atomicAdd(&dL_dvcolor[3 * v2 + c], g[6 + c]);
                 }
-                atomicAdd(&dL_dfopacity[curr_face], dop);
+                atomicAdd(&dL_dfopacity[curr_face], g[9]);
             }
 
             if (curr_face == first_face) done = true;
