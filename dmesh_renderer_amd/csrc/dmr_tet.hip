@@ -265,6 +265,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
 
     V3 C = {0, 0, 0};
     float D = 0.f, log_T = 0.f, prev_log_T = 0.f;
+    float T_cur = expf(log_T);  // expf(log_T), carried from step to step (the reference evaluates it twice per step)
     int last_face = -1, last_tet = -1;
     bool active = false;
     uint32_t n_contrib = 0;
@@ -276,7 +277,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         const float opacity = p.faces_opacity[curr_face];
         const float intense = p.faces_intense[(int64_t)b * p.F + curr_face];
         col = col * intense;
-        const float tmp_T = expf(log_T);
+        const float tmp_T = T_cur;  // expf(log_T): the value the previous step computed for its termination test
         C = C + tmp_T * opacity * col;
         const V3 pt = ro + (rd * curr_rt);
         const V4 pn = xform4x4(xform4x3(pt, mv), pr);
@@ -285,7 +286,8 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         prev_log_T = log_T;
         if (opacity < 1.0f) log_T += logf(1.0f - opacity);
         else log_T = logf(T_EPS * 0.1f);
-        if (expf(log_T) < T_EPS) { done = true; active = true; }
+        T_cur = expf(log_T);
+        if (T_cur < T_EPS) { done = true; active = true; }
         n_contrib++;
         last_face = curr_face;
         last_tet = curr_tet;
