@@ -5,8 +5,10 @@
 //
 // first_intersect walks the tile's min-depth-sorted face list in LDS-staged chunks (one
 // 16x16 tile per 256-thread workgroup, wave w = 8x8 quadrant w); the march kernels are one
-// thread per pixel with dependent gathers through tet_faces -> faces -> verts.
-// Rays are recomputed per pixel (seed <= 0 branch of generateRaysCUDA, forward.cu:124-127).
+// thread per pixel stepping through packed per-face / per-tet records (below) that every forward
+// rebuilds.  The backward sums per face in a per-tile LDS hash table (DPP-quad pre-reduction,
+// ds_add_f64) before touching HBM.  Rays are recomputed per pixel (generateRaysCUDA,
+// forward.cu:90-145; seeded jitter from a counter-based generator, dmr_device.hpp).
 // Guards: Q17 (no work when P/F/T == 0), Q18 (only pixels inside the image are touched),
 // Q19 (the unread is_active_backward diagnostic is dropped).
 #include <cstdlib>
