@@ -451,10 +451,27 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
                     g[c] = t;
                 }
             }
+            // ... then two such quads (row_half_mirror: 8 pixels in a row), then two such octets (row_mirror: two pixel
+            // rows), each time only if both halves are uniform and hold the same face.
+            const int kq = quad ? curr_face : -1;
+            const bool oct = quad && __builtin_amdgcn_update_dpp(-1, kq, 0x141, 0xF, 0xF, false) == curr_face;
+            if (oct) {
+#pragma unroll
+                for (int c = 0; c < 10; c++)
+                    g[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g[c]), 0x141, 0xF, 0xF, false));
+            }
+            const int ko = oct ? curr_face : -1;
+            const bool hex = oct && __builtin_amdgcn_update_dpp(-1, ko, 0x140, 0xF, 0xF, false) == curr_face;
+            if (hex) {
+#pragma unroll
+                for (int c = 0; c < 10; c++)
+                    g[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g[c]), 0x140, 0xF, 0xF, false));
+            }
+            const bool follower = hex ? (lane & 15) != 0 : (oct ? (lane & 7) != 0 : (quad && (lane & 3) != 0));
             // (DMR_ABLATE bit 2048, tests only: odd faces are refused a slot, which exercises the direct-atomic fallback)
-            const int slot = (quad && (lane & 3)) ? -2 : (((p.dbg & 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face));
+            const int slot = follower ? -2 : (((p.dbg & 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face));
             if (slot == -2) {
-                // this lane's values went out with lane (lane & ~3) of its quad
+                // this lane's values went out with the first lane of its quad / octet / row
             } else if (slot >= 0) {
 #pragma unroll
                 for (int c = 0; c < 10; c++) atomicAdd(&s_val[c][slot], (double)g[c]);
