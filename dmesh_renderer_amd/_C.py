@@ -24,6 +24,7 @@ import torch as th
 from . import _lib
 
 NUM_CHANNELS = 3  # cuda_*/config.h:4
+SUPPORTS_FLAT_OUT = True  # render_tris_backward(flat_out=...), used by sharding.py
 
 
 def _err(msg: str):

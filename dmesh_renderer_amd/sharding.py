@@ -103,9 +103,20 @@ class _ShardedTriFn(th.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_depth):
         saved = ctx.saved_tensors
-        g = ctx.impl.render_tris_backward(ctx.settings.bg, *saved[:10], grad_color, grad_depth, ctx.num_rendered,
-                                          *saved[10:14], rows=ctx.rows)
-        g_verts, g_vcolor, g_fopacity, g_vdepth, g_fintense = allreduce_grads(g, ctx.group)
+        if getattr(ctx.impl, "SUPPORTS_FLAT_OUT", False):
+            # the five gradients land back to back in one buffer: the all-reduce payload, no concatenation
+            verts, faces, mv = saved[0], saved[1], saved[4]
+            P, F, B = verts.size(0), faces.size(0), mv.size(0)
+            flat = th.empty(6 * P + F + B * (P + F), dtype=th.float32, device=verts.device)
+            g = ctx.impl.render_tris_backward(ctx.settings.bg, *saved[:10], grad_color, grad_depth, ctx.num_rendered,
+                                              *saved[10:14], rows=ctx.rows, flat_out=flat)
+            if dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+            g_verts, g_vcolor, g_fopacity, g_vdepth, g_fintense = g
+        else:
+            g = ctx.impl.render_tris_backward(ctx.settings.bg, *saved[:10], grad_color, grad_depth, ctx.num_rendered,
+                                              *saved[10:14], rows=ctx.rows)
+            g_verts, g_vcolor, g_fopacity, g_vdepth, g_fintense = allreduce_grads(g, ctx.group)
         return (g_verts, None, g_vcolor, g_fopacity, None, None, g_vdepth, g_fintense) + (None,) * 5
 
 
