@@ -3,7 +3,10 @@
     python -m dmesh_renderer_amd.build [--force]
 
 hipcc cross-compiles gfx950 without a GPU.  -ffp-contract=off is part of the product's
-FP contract (see csrc/dmr_device.hpp), not a debugging flag.
+FP contract (see csrc/dmr_device.hpp), not a debugging flag.  -fno-slp-vectorize keeps the
+compiler from pairing scalar f32 math into v_pk_* instructions: on gfx950 a packed op costs
+~1.7x a scalar one and needs v_mov shuffles to form its operand pairs (scripts/micro/valu_rates.hip;
+k_tri_forward 72 -> 63 us, k_tri_backward_hits 149 -> 134 us at C4 without it).
 """
 from __future__ import annotations
 
@@ -38,7 +41,7 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB + ".tmp"]
     cmd += os.environ.get("DMR_HIPCC_FLAGS", "").split()  # tuning experiments only
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
