@@ -314,6 +314,13 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face
 // measured length distribution).
 constexpr int ORDER_BUCKETS = 64;
 __device__ __forceinline__ int order_bucket(uint32_t n) { return ORDER_BUCKETS - 1 - (int)min(n >> 4, (uint32_t)(ORDER_BUCKETS - 1)); }
+// Neighbouring tiles have lists of similar length, so the lanes of a wave mostly want the SAME bucket, and same-address
+// LDS atomics retire one lane at a time (scripts/micro/lds_atomics.hip): 16 waves x 8 tiles x 64 lanes in a row, twice,
+// were 8 of k_scan_tiles' 18 us.  Every bucket therefore has ORDER_COPIES counters, picked by lane: at most four lanes
+// of a wave meet on one.  The order inside a bucket is arbitrary anyway.
+constexpr int ORDER_COPIES = 16;
+constexpr int ORDER_CELLS = ORDER_BUCKETS * ORDER_COPIES;  // + 1 cell for the empty tiles, behind all the others
+__device__ __forceinline__ int order_cell(uint32_t n, int lane) { return order_bucket(n) * ORDER_COPIES + (lane & (ORDER_COPIES - 1)); }
 
 // Both scans are one 1024-thread workgroup (n = B * tiles is small, C4: 8160).  Their time is the chain of
 // dependent global-memory round trips, so a thread fetches its items SCAN_BATCH at a time with independent loads
@@ -345,75 +352,90 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, int tid
     return wave_sum[wave] + incl - local;  // total in wave_sum[16]
 }
 
+// One workgroup has one memory pipeline: a thread touching its 8 consecutive tiles directly (32-byte stride across a
+// wave) made every lane a request of its own -- 24 stores + 16 loads per thread, 11 of the kernel's 17 us in the
+// store pass alone.  So the tiles go through an LDS slab: coalesced global loads in, 16-byte LDS reads per thread, and
+// offsets / order are written back to the slab and leave as coalesced stores.
+constexpr int SCAN_SLAB = 1024 * SCAN_BATCH;  // tiles one workgroup scans (LDS: 32 KB)
+
+__device__ __forceinline__ void slab_load(uint32_t* __restrict__ slab, const uint32_t* __restrict__ src, int n, int tid) {
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) { const int i = j * 1024 + tid; slab[i] = i < n ? src[i] : 0u; }
+}
+__device__ __forceinline__ void slab_read(const uint32_t* __restrict__ slab, int tid, uint32_t (&c)[SCAN_BATCH]) {
+    static_assert(SCAN_BATCH == 8, "two 16-byte LDS reads per thread");
+    const uint4 lo = *reinterpret_cast<const uint4*>(slab + tid * SCAN_BATCH), hi = *reinterpret_cast<const uint4*>(slab + tid * SCAN_BATCH + 4);
+    c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+}
+// the thread's exclusive running offsets, starting at `run`, over its own slots of the slab
+__device__ __forceinline__ void slab_write_offsets(uint32_t* __restrict__ slab, int tid, uint32_t run, const uint32_t (&c)[SCAN_BATCH]) {
+    uint32_t o[SCAN_BATCH];
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) { o[j] = run; run += c[j]; }
+    *reinterpret_cast<uint4*>(slab + tid * SCAN_BATCH) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(slab + tid * SCAN_BATCH + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
              uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered, int* __restrict__ host_num_rendered,
              uint32_t* __restrict__ tile_order) {
+    static_assert(ORDER_CELLS == 1024, "one counter cell per thread");
     __shared__ uint32_t wave_sum[17];
-    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];  // [ORDER_BUCKETS]: empty tiles, behind all the others
+    __shared__ uint32_t bucket[ORDER_CELLS + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t slab[SCAN_SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int per = (n + 1023) / 1024;
-    const int begin = min(n, tid * per), end = min(n, begin + per);
-    if (tid <= ORDER_BUCKETS) bucket[tid] = 0u;
+    const int begin = tid * SCAN_BATCH;  // n <= SCAN_SLAB
+    bucket[tid] = 0u;
+    slab_load(slab, tile_count, n, tid);
     __syncthreads();
-    uint32_t local = 0;
-    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
-        uint32_t c[SCAN_BATCH];
+    uint32_t c[SCAN_BATCH], local = 0;
+    slab_read(slab, tid, c);
 #pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_count[i0 + j] : 0u;
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) {
-            local += c[j];
-            // empty tiles (most of a frame) would all hit one LDS counter: they are counted per wave instead
-            const bool empty = i0 + j < end && c[j] == 0u;
-            const uint64_t em = __ballot(empty);
-            if (em && lane == __ffsll((long long)em) - 1) atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
-            if (i0 + j < end && c[j]) atomicAdd(&bucket[order_bucket(c[j])], 1u);
-        }
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        local += c[j];
+        if (c[j]) atomicAdd(&bucket[order_cell(c[j], lane)], 1u);  // empty tiles: what is left over
     }
-    uint32_t run = block_exclusive_scan(local, tid, wave_sum);
-    if (tid < 64) {  // exclusive scan of the bucket sizes: bucket 0 holds the longest lists, empty tiles come last
-        const uint32_t c = bucket[lane];
-        uint32_t bi = c;
+    const uint32_t run = block_exclusive_scan(local, tid, wave_sum);
+    const uint32_t total = wave_sum[16];
+    slab_write_offsets(slab, tid, run, c);
+    __syncthreads();  // wave_sum is reused; the offsets are in the slab
+    // exclusive scan of the cells (bucket-major): bucket 0 holds the longest lists, empty tiles come last
+    const uint32_t cell_base = block_exclusive_scan(bucket[tid], tid, wave_sum);
+    bucket[tid] = cell_base;
+    if (tid == 0) bucket[ORDER_CELLS] = wave_sum[16];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(bi, d, 64);
-            if (lane >= d) bi += o;
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        const int i = j * 1024 + tid;
+        if (i < n) { const uint32_t o = slab[i]; tile_offset[i] = o; tile_cursor[i] = o; }
+    }
+    __syncthreads();  // the cells are final; the slab is free
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        const bool in = begin + j < n;
+        const bool empty = in && c[j] == 0u;
+        const uint64_t em = __ballot(empty);  // empty tiles (most of a frame) share one cell: claimed per wave
+        uint32_t ebase = 0;
+        if (em) {
+            const int leader = __ffsll((long long)em) - 1;
+            if (lane == leader) ebase = atomicAdd(&bucket[ORDER_CELLS], (uint32_t)__popcll(em));
+            ebase = __shfl(ebase, leader, 64);
         }
-        bucket[lane] = bi - c;
-        if (lane == 63) bucket[ORDER_BUCKETS] = bi;
+        if (empty) slab[ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)(begin + j);
+        else if (in) slab[atomicAdd(&bucket[order_cell(c[j], lane)], 1u)] = (uint32_t)(begin + j);
     }
     __syncthreads();
-    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
-        uint32_t c[SCAN_BATCH];
 #pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_count[i0 + j] : 0u;
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) {
-            const bool in = i0 + j < end;
-            if (in) { tile_offset[i0 + j] = run; tile_cursor[i0 + j] = run; }
-            run += c[j];
-            const bool empty = in && c[j] == 0u;
-            const uint64_t em = __ballot(empty);
-            uint32_t ebase = 0;
-            if (em) {
-                const int leader = __ffsll((long long)em) - 1;
-                if (lane == leader) ebase = atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
-                ebase = __shfl(ebase, leader, 64);
-            }
-            if (empty) tile_order[ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)(i0 + j);
-            else if (in) tile_order[atomicAdd(&bucket[order_bucket(c[j])], 1u)] = (uint32_t)(i0 + j);
-        }
-    }
+    for (int j = 0; j < SCAN_BATCH; j++) { const int i = j * 1024 + tid; if (i < n) tile_order[i] = slab[i]; }
     // host_num_rendered: pinned host memory, read by the host after the event recorded behind this kernel
-    if (tid == 0) { tile_offset[n] = wave_sum[16]; *num_rendered = (int)wave_sum[16]; *host_num_rendered = (int)wave_sum[16]; }
+    if (tid == 0) { tile_offset[n] = total; *num_rendered = (int)total; *host_num_rendered = (int)total; }
 }
 
 // ---- the same for many tiles (B * tiles > SCAN_SINGLE_MAX: several views at 1080p, 4096^2 images): one workgroup
 // per 8192 tiles, three small launches (partial sums + bucket sizes | scan of the partials | offsets + order) instead
 // of one workgroup streaming everything (0.5 ms for C5's 1 M tiles).
 constexpr int SCAN_BLOCK_TILES = 8192;
-constexpr int SCAN_SINGLE_MAX = 16384;   // up to here one workgroup does it all (k_scan_tiles)
+constexpr int SCAN_SINGLE_MAX = SCAN_SLAB;   // up to here one workgroup does it all (k_scan_tiles, k_scan_hits)
 
 // pass 1: blk_sum[block] = sum of the block's counts; bucket_count[b] += tiles of the block in order bucket b
 template <bool ORDER>
@@ -421,10 +443,10 @@ __global__ void __launch_bounds__(1024)
 k_scan_tiles_partial(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ blk_sum,
                      uint32_t* __restrict__ bucket_count) {
     __shared__ uint32_t wave_sum[17];
-    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
+    __shared__ uint32_t bucket[ORDER_CELLS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int begin = min(n, (int)blockIdx.x * SCAN_BLOCK_TILES + tid * SCAN_BATCH), end = min(n, begin + SCAN_BATCH);
-    if (tid <= ORDER_BUCKETS) bucket[tid] = 0u;
+    if (ORDER) bucket[tid] = 0u;
     __syncthreads();
     uint32_t c[SCAN_BATCH], local = 0;
 #pragma unroll
@@ -432,16 +454,16 @@ k_scan_tiles_partial(int n, const uint32_t* __restrict__ tile_count, uint32_t* _
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) {
         local += c[j];
-        if (ORDER) {
-            const bool empty = begin + j < end && c[j] == 0u;
-            const uint64_t em = __ballot(empty);
-            if (em && lane == __ffsll((long long)em) - 1) atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
-            if (begin + j < end && c[j]) atomicAdd(&bucket[order_bucket(c[j])], 1u);
-        }
+        if (ORDER && begin + j < end && c[j]) atomicAdd(&bucket[order_cell(c[j], lane)], 1u);
     }
-    block_exclusive_scan(local, tid, wave_sum);
+    block_exclusive_scan(local, tid, wave_sum);  // (its barriers also publish the cells)
     if (tid == 0) blk_sum[blockIdx.x] = wave_sum[16];
-    if (ORDER && tid <= ORDER_BUCKETS && bucket[tid]) atomicAdd(&bucket_count[tid], bucket[tid]);
+    if (ORDER && tid < ORDER_BUCKETS) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < ORDER_COPIES; q++) cnt += bucket[tid * ORDER_COPIES + q];
+        if (cnt) atomicAdd(&bucket_count[tid], cnt);
+    }
 }
 
 // pass 2 (one workgroup): blk_sum -> exclusive scan in place, total -> R; bucket_count -> exclusive scan in place
@@ -485,27 +507,39 @@ k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_
                    uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
                    uint32_t* __restrict__ tile_order) {
     __shared__ uint32_t wave_sum[17];
-    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
+    __shared__ uint32_t bucket[ORDER_CELLS + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int begin = min(n, (int)blockIdx.x * SCAN_BLOCK_TILES + tid * SCAN_BATCH), end = min(n, begin + SCAN_BATCH);
-    if (tid <= ORDER_BUCKETS) bucket[tid] = 0u;
+    if (ORDER) { bucket[tid] = 0u; if (tid == 0) bucket[ORDER_CELLS] = 0u; }
     __syncthreads();
     uint32_t c[SCAN_BATCH], local = 0;
+    int n_empty = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) c[j] = begin + j < end ? tile_count[begin + j] : 0u;
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) {
         local += c[j];
-        if (ORDER) {
-            const bool empty = begin + j < end && c[j] == 0u;
-            const uint64_t em = __ballot(empty);
-            if (em && lane == __ffsll((long long)em) - 1) atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
-            if (begin + j < end && c[j]) atomicAdd(&bucket[order_bucket(c[j])], 1u);
+        if (ORDER && begin + j < end) {
+            if (c[j]) atomicAdd(&bucket[order_cell(c[j], lane)], 1u);
+            else n_empty++;
         }
     }
+    if (ORDER) {  // empty tiles of the block: one LDS add per wave
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) n_empty += __shfl_xor(n_empty, d, 64);
+        if (lane == 0 && n_empty) atomicAdd(&bucket[ORDER_CELLS], (uint32_t)n_empty);
+    }
     uint32_t run = blk_sum[blockIdx.x] + block_exclusive_scan(local, tid, wave_sum);
-    // claim the block's share of every bucket of the global order; the LDS bins then hand out slots
-    if (ORDER && tid <= ORDER_BUCKETS) { const uint32_t cnt = bucket[tid]; bucket[tid] = cnt ? atomicAdd(&bucket_cursor[tid], cnt) : 0u; }
+    // claim the block's share of every bucket of the global order; the LDS cells then hand out slots
+    if (ORDER && tid < ORDER_BUCKETS) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < ORDER_COPIES; q++) cnt += bucket[tid * ORDER_COPIES + q];
+        uint32_t base = cnt ? atomicAdd(&bucket_cursor[tid], cnt) : 0u;
+#pragma unroll
+        for (int q = 0; q < ORDER_COPIES; q++) { const uint32_t k = bucket[tid * ORDER_COPIES + q]; bucket[tid * ORDER_COPIES + q] = base; base += k; }
+    }
+    if (ORDER && tid == ORDER_BUCKETS) { const uint32_t cnt = bucket[ORDER_CELLS]; bucket[ORDER_CELLS] = cnt ? atomicAdd(&bucket_cursor[ORDER_BUCKETS], cnt) : 0u; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) {
@@ -518,11 +552,11 @@ k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_
         uint32_t ebase = 0;
         if (em) {
             const int leader = __ffsll((long long)em) - 1;
-            if (lane == leader) ebase = atomicAdd(&bucket[ORDER_BUCKETS], (uint32_t)__popcll(em));
+            if (lane == leader) ebase = atomicAdd(&bucket[ORDER_CELLS], (uint32_t)__popcll(em));
             ebase = __shfl(ebase, leader, 64);
         }
         if (empty) tile_order[ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)(begin + j);
-        else if (in) tile_order[atomicAdd(&bucket[order_bucket(c[j])], 1u)] = (uint32_t)(begin + j);
+        else if (in) tile_order[atomicAdd(&bucket[order_cell(c[j], lane)], 1u)] = (uint32_t)(begin + j);
     }
 }
 
@@ -533,32 +567,25 @@ k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, uint32_t* __restrict_
             unsigned long long* __restrict__ hit_total, unsigned long long* __restrict__ host_hit_total) {
     __shared__ uint32_t wave_sum[17];
     __shared__ unsigned long long s_total;
+    __shared__ __attribute__((aligned(16))) uint32_t slab[SCAN_SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int per = (n + 1023) / 1024;
-    const int begin = min(n, tid * per), end = min(n, begin + per);
     if (tid == 0) s_total = 0ull;
-    uint32_t c[SCAN_BATCH];
-    uint32_t local = 0; unsigned long long wide = 0;
-    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
+    slab_load(slab, tile_hits, n, tid);  // n <= SCAN_SLAB
+    __syncthreads();
+    uint32_t c[SCAN_BATCH], local = 0;
+    slab_read(slab, tid, c);
+    unsigned long long wide = 0;
 #pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_hits[i0 + j] : 0u;
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) { local += c[j]; wide += c[j]; }
-    }
+    for (int j = 0; j < SCAN_BATCH; j++) { local += c[j]; wide += c[j]; }
     // 64-bit total (overflow check on the host); the offsets themselves wrap harmlessly in that case
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) wide += __shfl_xor(wide, d, 64);
-    uint32_t run = block_exclusive_scan(local, tid, wave_sum);
+    const uint32_t run = block_exclusive_scan(local, tid, wave_sum);
     if (lane == 0) atomicAdd(&s_total, wide);
-    for (int i0 = begin; i0 < end; i0 += SCAN_BATCH) {
-        if (per > SCAN_BATCH) {
-#pragma unroll
-            for (int j = 0; j < SCAN_BATCH; j++) c[j] = i0 + j < end ? tile_hits[i0 + j] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) { if (i0 + j < end) hit_offset[i0 + j] = run; run += c[j]; }
-    }
+    slab_write_offsets(slab, tid, run, c);
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) { const int i = j * 1024 + tid; if (i < n) hit_offset[i] = slab[i]; }
     if (tid == 0) { hit_offset[n] = wave_sum[16]; *hit_total = s_total; *host_hit_total = s_total; }
 }
 
