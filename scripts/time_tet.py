@@ -5,7 +5,7 @@ import numpy as np, torch as th
 from dmesh_renderer_amd import _C, _lib, scenes
 
 ap = argparse.ArgumentParser(); ap.add_argument("--m", type=int, default=16); ap.add_argument("--size", type=int, default=800)
-ap.add_argument("--steps", type=int, default=10); ap.add_argument("--check", action="store_true")
+ap.add_argument("--steps", type=int, default=10)
 a = ap.parse_args()
 dev = th.device("cuda:0"); H = W = a.size
 d = scenes.kuhn_tets(a.m, 1, H, W)
@@ -25,9 +25,3 @@ ms = (C.c_double * _lib.NUM_STAGES)(); cnt = (C.c_int64 * _lib.NUM_STAGES)(); li
 st = {lib.dmr_stage_name(i).decode(): round(ms[i] / cnt[i], 4) for i in range(_lib.NUM_STAGES) if cnt[i]}
 print(json.dumps({"tets": int(d["tets"].shape[0]), "faces": int(d["faces"].shape[0]), "image": [H, W], "ms_per_step": round(dt * 1e3, 4),
                   "Mpix_s": round(H * W / dt / 1e6, 1), "active_frac": round(float(o[2].mean()), 3), "stages_ms": st}))
-if a.check:
-    from oracle import oracle as O
-    sc = O.scene_from_module_inputs(d, H, W)
-    t1 = time.perf_counter(); oc, od, oa, ost = O.tet_forward(sc); og = O.tet_backward(sc, ost, gc.cpu().numpy(), gd.cpu().numpy()); ct = time.perf_counter() - t1
-    print(json.dumps({"cpu_s": round(ct, 2), "fwd_err": float(np.abs(o[0].cpu().numpy() - oc).max()), "active_equal": bool(np.array_equal(o[2].cpu().numpy(), oa)),
-                      "grad_err": max(scenes.rel_err(g[0].cpu().numpy(), og["verts_color"]), scenes.rel_err(g[1].cpu().numpy(), og["faces_opacity"]))}))

@@ -1,6 +1,6 @@
-"""Per-tensor forward/gradient error of the tri path against the CPU oracle (debug aid)."""
+"""Test infrastructure. Per-tensor forward/gradient error of the tri path against the CPU oracle (debug aid)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch as th
 from dmesh_renderer_amd import _C, scenes
 from oracle import oracle as O
