@@ -24,8 +24,12 @@ CASES = {
     "dense": (12, 9, 1, 64, 64, (0.05, 0.3)),               # long tile lists: several LDS chunks per tile
     # 5120 faces over 4 tiles: lists longer than the sort's LDS capacity (in-place bitonic network in HBM), 40 chunks
     "very_dense": (40, 9, 1, 32, 32, (0.01, 0.08)),
-    # 2 x 96 x 96 = 18 432 tiles: the multi-workgroup tile scans (more than 16 384 tiles) and windowed binning
+    # 2 x 96 x 96 = 18 432 tiles: the multi-workgroup tile scans (more than 8 192 tiles) and windowed binning
     "many_tiles": (3, 24, 2, 1536, 1536, (0.1, 0.5)),
+    # 90 x 91 = 8 190 tiles: the single-workgroup scans with their LDS slab (8 192 tiles) all but full, and
+    # 91 x 92 = 8 372 tiles: two scan workgroups, the second one nearly empty
+    "slab_full": (3, 20, 1, 1440, 1456, (0.1, 0.5)),
+    "two_scan_blocks": (3, 20, 1, 1456, 1472, (0.1, 0.5)),
     # 300 consecutive screen-filling triangles (400 tiles each): more than the binning kernels' LDS queue of big
     # faces holds per workgroup (128), so both the cooperative emission and its per-thread fallback run
     "many_big": (150, 2, 1, 320, 320, (0.005, 0.02)),
