@@ -24,8 +24,9 @@ static_assert(sizeof(HitRec) == 48, "HitRec");
 
 struct alignas(16) TetFaceRec { float p0[3], p1[3], p2[3], n[3]; int ft0, ft1; float opacity; int pad; };
 static_assert(sizeof(TetFaceRec) == 64, "TetFaceRec");
-struct alignas(16) TetColRec { float c0[3], c1[3], c2[3]; int v0, v1, v2; };
-static_assert(sizeof(TetColRec) == 48, "TetColRec");
+// log1m = logf(1 - opacity), evaluated once per face by the same device function the march would call per step
+struct alignas(16) TetColRec { float c0[3], c1[3], c2[3]; int v0, v1, v2; float opacity, log1m; int pad[2]; };
+static_assert(sizeof(TetColRec) == 64, "TetColRec");
 
 struct TetParams {
     int B, P, F, W, H, gx, gy, r0, dbg;
@@ -45,7 +46,7 @@ struct TetParams {
 // centre, then four normalised outward normals (sqrt + divide each).  Everything that does not depend
 // on the ray is hoisted here, with the reference's arithmetic, so the decisions stay bit-identical:
 //   TetFaceRec : the three vertices, the UNIT normal before orientation, face_tets, opacity -- one 64-byte line
-//   TetColRec  : the three vertex colours
+//   TetColRec  : the three vertex colours and ids, the opacity and logf(1 - opacity) -- one 64-byte line
 //   tetrec     : the four faces of a tet, bit 31 set where tet_face_outward_normal flips the unit normal
 //                (dot(n, centre - p0) > 0, cuda_renderer/auxiliary.h:386-392); dot(-n, d) == -dot(n, d) exactly.
 // A step is then tetrec -> 3 x TetFaceRec: two dependent levels of 16-byte loads.
@@ -78,6 +79,7 @@ k_tet_prep_faces(int F, const float* __restrict__ verts, const int* __restrict__
     c.c1[0] = c1.x; c.c1[1] = c1.y; c.c1[2] = c1.z;
     c.c2[0] = c2.x; c.c2[1] = c2.y; c.c2[2] = c2.z;
     c.v0 = v0; c.v1 = v1; c.v2 = v2;
+    c.opacity = r.opacity; c.log1m = logf(1.0f - r.opacity); c.pad[0] = c.pad[1] = 0;
     colrec[f] = c;
 }
 
@@ -273,10 +275,10 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     uint32_t n_contrib = 0;
     while (!done) {
         const float4* cq = reinterpret_cast<const float4*>(p.colrec + curr_face);
-        const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2];
+        const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2], cq3 = cq[3];
         const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
         V3 col = (c0 + (c1 - c0) * curr_iu + (c2 - c0) * curr_iv);  // Q21
-        const float opacity = p.faces_opacity[curr_face];
+        const float opacity = cq3.x;
         const float intense = p.faces_intense[(int64_t)b * p.F + curr_face];
         col = col * intense;
         const float tmp_T = T_cur;  // expf(log_T): the value the previous step computed for its termination test
@@ -286,7 +288,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         const float pw = 1.0f / clamp_w(pn.w);
         D += tmp_T * opacity * (pn.z * pw);
         prev_log_T = log_T;
-        if (opacity < 1.0f) log_T += logf(1.0f - opacity);
+        if (opacity < 1.0f) log_T += cq3.y;  // logf(1 - opacity), per face (TetColRec)
         else log_T = logf(T_EPS * 0.1f);
         T_cur = expf(log_T);
         if (T_cur < T_EPS) { done = true; active = true; }
@@ -397,19 +399,19 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
         bool first_iter = true, done = false;
         while (!done) {
             const float4* cq = reinterpret_cast<const float4*>(p.colrec + curr_face);
-            const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2];
+            const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2], cq3 = cq[3];
             const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
             const int v0 = __float_as_int(cq2.y), v1 = __float_as_int(cq2.z), v2 = __float_as_int(cq2.w);
             const float i0 = 1.0f - curr_iu - curr_iv, i1 = curr_iu, i2 = curr_iv;
             V3 col = (i0 * c0) + (i1 * c1) + (i2 * c2);  // Q21
-            const float opacity = p.faces_opacity[curr_face];
+            const float opacity = cq3.x;
             const float intense = p.faces_intense[(int64_t)b * p.F + curr_face];
             col = col * intense;
             const V3 pt = ro + (rd * curr_rt);
             const V4 pn = xform4x4(xform4x3(pt, mv), pr);
             const float pw = 1.0f / clamp_w(pn.w);
             const float pdepth = pn.z * pw;
-            if (!first_iter) prev_log_T = prev_log_T - logf(1.0f - opacity);
+            if (!first_iter) prev_log_T = prev_log_T - cq3.y;  // logf(1 - opacity), per face (TetColRec)
             first_iter = false;
             const float prev_T = expf(prev_log_T);
 
