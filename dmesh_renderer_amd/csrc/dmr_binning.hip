@@ -71,7 +71,7 @@ k_project_verts(int B, int P, const float* __restrict__ verts, const float* __re
 //   scatter every (face, tile) pair into its tile's segment, key = depth_bits << 32 | face_id (scatter).
 //   rect is kept (packed 4 x u16) so the scatter pass does not redo the float work.
 //   Global u32 atomics on ~3000 hot tile counters were the cost of both passes (69 + 80 us at C4 for
-//   0.9 M increments; 0.46 + 0.65 ms at C5).  Here a workgroup takes BIN_FACES consecutive faces, counts them
+//   0.9 M increments; 0.46 + 0.65 ms at C5).  Here a workgroup takes 256 x FPT consecutive faces, counts them
 //   into an LDS histogram (ds_add_u32), and touches global memory once per (workgroup, non-empty tile): the count
 //   pass adds the bin, the scatter pass reserves the bin's slots with ONE returning atomic and then hands
 //   out slots with returning LDS atomics.  The histogram covers a WINDOW of tiles: the bounding box of the
@@ -80,7 +80,11 @@ k_project_verts(int B, int P, const float* __restrict__ verts, const float* __re
 //   view and whole workgroups whose box exceeds LDS_HIST_MAX tiles use the global counters directly.
 // ---------------------------------------------------------------------------
 constexpr int LDS_HIST_MAX = 8192;    // 32 KiB of counters
-constexpr int BIN_FACES = 1024;       // faces per workgroup (4 per thread)
+// Faces per thread (FPT): 4 for large meshes -- a long run of consecutive faces per workgroup amortises the window's
+// set-up and global atomics -- and 1 when that would leave the chip empty (C3's 50 688 faces are 50 workgroups of
+// 1024 faces, each thread looping over four 4x4-tile rects: scatter 34 us; 198 workgroups: see DESIGN.md).
+constexpr int BIN_FPT_MAX = 4;
+constexpr int64_t BIN_SMALL_MESH = 256 * 1024;  // below this many (view, face) pairs: FPT = 1
 constexpr uint32_t BIG_RECT = 256;    // tiles; larger rects go straight to global atomics
 
 struct BinWindow { int x0, y0, wx, wy, view; bool lds; };
@@ -111,11 +115,12 @@ struct RectWalk {
 // s_box: {min x, min y, max x, max y} of the rects that want the LDS histogram; uniform result.  Threads reduce
 // their own faces, waves reduce with shuffles, one lane per wave touches LDS (every thread doing ds_min / ds_max on
 // the same four words serialises: 2 cycles per lane and atomic).
+template <int FPT>
 __device__ __forceinline__ BinWindow bin_window(int* s_box, int view, const uint2* rr, const uint32_t* touched,
                                                 const bool* mine, int tid) {
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = 0, by1 = 0;
 #pragma unroll
-    for (int it = 0; it < BIN_FACES / 256; it++) {
+    for (int it = 0; it < FPT; it++) {
         if (!mine[it] || touched[it] == 0 || touched[it] > BIG_RECT) continue;
         bx0 = min(bx0, (int)(rr[it].x & 0xffffu)); by0 = min(by0, (int)(rr[it].x >> 16));
         bx1 = max(bx1, (int)(rr[it].y & 0xffffu)); by1 = max(by1, (int)(rr[it].y >> 16));
@@ -138,7 +143,7 @@ __device__ __forceinline__ BinWindow bin_window(int* s_box, int view, const uint
     return w;
 }
 
-template <bool TET>
+template <bool TET, int FPT>
 __global__ void __launch_bounds__(256)
 k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const float4* __restrict__ vproj,
                   int gx, int gy, int r0, int r1,
@@ -151,13 +156,13 @@ k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const floa
     const int tid = threadIdx.x;
     if (tid == 0) s_nbig = 0u;  // (bin_window's barriers order this before the queueing below)
     const int64_t BF = (int64_t)B * F;
-    const int64_t base = (int64_t)blockIdx.x * BIN_FACES;
+    const int64_t base = (int64_t)blockIdx.x * (256 * FPT);
     const int view = (int)(base / F);
-    uint2 rr[BIN_FACES / 256];
-    uint32_t touched[BIN_FACES / 256];
-    bool mine[BIN_FACES / 256];  // face of the window's view
+    uint2 rr[FPT];
+    uint32_t touched[FPT];
+    bool mine[FPT];  // face of the window's view
 #pragma unroll
-    for (int it = 0; it < BIN_FACES / 256; it++) {
+    for (int it = 0; it < FPT; it++) {
         const int64_t idx = base + it * 256 + tid;
         touched[it] = 0u; rr[it] = make_uint2(0, 0); mine[it] = false;
         if (idx >= BF) continue;
@@ -183,12 +188,12 @@ k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const floa
         key_depth[idx] = touched[it] ? (TET ? map01(min_z) : map01(depth)) : 0.0f;
         if (TET) max_depth[idx] = touched[it] ? map01(max_z) : 0.0f;
     }
-    const BinWindow w = bin_window(s_box, view, rr, touched, mine, tid);
+    const BinWindow w = bin_window<FPT>(s_box, view, rr, touched, mine, tid);
     const int nw = w.wx * w.wy;
     for (int t = tid; t < nw; t += 256) s_hist[t] = 0u;
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < BIN_FACES / 256; it++) {
+    for (int it = 0; it < FPT; it++) {
         if (touched[it] == 0) continue;
         const int64_t idx = base + it * 256 + tid;
         const uint32_t tb = (uint32_t)(idx / F) * gx * gy;
@@ -219,6 +224,7 @@ k_setup_faces_lds(int B, int P, int F, const int* __restrict__ faces, const floa
     }
 }
 
+template <int FPT>
 __global__ void __launch_bounds__(256)
 k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face_rect,
                     const float* __restrict__ key_depth, const uint32_t* __restrict__ tiles_touched,
@@ -230,25 +236,25 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face
     const int tid = threadIdx.x;
     if (tid == 0) s_nbig = 0u;
     const int64_t BF = (int64_t)B * F;
-    const int64_t base = (int64_t)blockIdx.x * BIN_FACES;
+    const int64_t base = (int64_t)blockIdx.x * (256 * FPT);
     const int view = (int)(base / F);
-    uint2 rr[BIN_FACES / 256];
-    uint32_t touched[BIN_FACES / 256];
-    bool mine[BIN_FACES / 256];
+    uint2 rr[FPT];
+    uint32_t touched[FPT];
+    bool mine[FPT];
 #pragma unroll
-    for (int it = 0; it < BIN_FACES / 256; it++) {
+    for (int it = 0; it < FPT; it++) {
         const int64_t idx = base + it * 256 + tid;
         touched[it] = idx < BF ? tiles_touched[idx] : 0u;
         rr[it] = touched[it] ? face_rect[idx] : make_uint2(0, 0);
         mine[it] = idx < BF && (int)(idx / F) == view;
     }
-    const BinWindow w = bin_window(s_box, view, rr, touched, mine, tid);
+    const BinWindow w = bin_window<FPT>(s_box, view, rr, touched, mine, tid);
     const int nw = w.wx * w.wy;
     for (int t = tid; t < nw; t += 256) s_hist[t] = 0u;
     __syncthreads();
     // pass 1: count this workgroup's entries per tile of the window
 #pragma unroll
-    for (int it = 0; it < BIN_FACES / 256; it++) {
+    for (int it = 0; it < FPT; it++) {
         if (!(w.lds && mine[it]) || touched[it] == 0 || touched[it] > BIG_RECT) continue;
         const uint32_t minx = rr[it].x & 0xffffu, miny = rr[it].x >> 16, maxx = rr[it].y & 0xffffu, maxy = rr[it].y >> 16;
         for (uint32_t y = miny; y < maxy; y++)
@@ -264,7 +270,7 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face
     __syncthreads();
     // pass 2: hand out slots
 #pragma unroll
-    for (int it = 0; it < BIN_FACES / 256; it++) {
+    for (int it = 0; it < FPT; it++) {
         if (touched[it] == 0) continue;
         const int64_t idx = base + it * 256 + tid;
         const int f = (int)(idx % F);
@@ -718,13 +724,13 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
     StageScope t(DMR_STAGE_SETUP_FACES, st);
-    dim3 grid((unsigned)((n + BIN_FACES - 1) / BIN_FACES)), block(256);
-    if (tet)
-        k_setup_faces_lds<true><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect, key_depth,
-                                                        max_depth, tiles_touched, tile_count);
-    else
-        k_setup_faces_lds<false><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, face_rect, key_depth,
-                                                         max_depth, tiles_touched, tile_count);
+    const int fpt = n < BIN_SMALL_MESH ? 1 : BIN_FPT_MAX;
+    dim3 grid((unsigned)((n + 256 * fpt - 1) / (256 * fpt))), block(256);
+#define DMR_SETUP(TET, FPT) k_setup_faces_lds<TET, FPT><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, \
+                                face_rect, key_depth, max_depth, tiles_touched, tile_count)
+    if (tet) { if (fpt == 1) DMR_SETUP(true, 1); else DMR_SETUP(true, BIN_FPT_MAX); }
+    else { if (fpt == 1) DMR_SETUP(false, 1); else DMR_SETUP(false, BIN_FPT_MAX); }
+#undef DMR_SETUP
 }
 
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
@@ -767,8 +773,12 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
     StageScope t(DMR_STAGE_SCATTER, st);
-    k_scatter_faces_lds<<<dim3((unsigned)((n + BIN_FACES - 1) / BIN_FACES)), dim3(256), 0, st>>>(
-        s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
+    if (n < BIN_SMALL_MESH)
+        k_scatter_faces_lds<1><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
+            s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
+    else
+        k_scatter_faces_lds<BIN_FPT_MAX><<<dim3((unsigned)((n + 256 * BIN_FPT_MAX - 1) / (256 * BIN_FPT_MAX))), dim3(256), 0, st>>>(
+            s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
 }
 
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
