@@ -81,10 +81,10 @@ k_project_verts(int B, int P, const float* __restrict__ verts, const float* __re
 // ---------------------------------------------------------------------------
 constexpr int LDS_HIST_MAX = 8192;    // 32 KiB of counters
 // Faces per thread (FPT): 4 for large meshes -- a long run of consecutive faces per workgroup amortises the window's
-// set-up and global atomics -- and 1 when that would leave the chip empty (C3's 50 688 faces are 50 workgroups of
-// 1024 faces, each thread looping over four 4x4-tile rects: scatter 34 us; 198 workgroups: see DESIGN.md).
-constexpr int BIN_FPT_MAX = 4;
-constexpr int64_t BIN_SMALL_MESH = 256 * 1024;  // below this many (view, face) pairs: FPT = 1
+// set-up and global atomics -- fewer when that would leave the chip empty: C3's 50 688 faces were 50 workgroups of
+// 1024 faces, each thread looping over four 4x4-tile rects (scatter 34 us, 14 us with one face per thread); C4's
+// 500 000 faces: set-up / scatter 14.8 / 17.7 us at FPT 4, 13.2 / 14.5 at 2, 14.5 / 16.9 at 1; C5's 8 M: FPT 4.
+__host__ inline int bin_fpt(int64_t n) { return n < 256 * 1024 ? 1 : n < 1024 * 1024 ? 2 : 4; }
 constexpr uint32_t BIG_RECT = 256;    // tiles; larger rects go straight to global atomics
 
 struct BinWindow { int x0, y0, wx, wy, view; bool lds; };
@@ -724,12 +724,12 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
     StageScope t(DMR_STAGE_SETUP_FACES, st);
-    const int fpt = n < BIN_SMALL_MESH ? 1 : BIN_FPT_MAX;
+    const int fpt = bin_fpt(n);
     dim3 grid((unsigned)((n + 256 * fpt - 1) / (256 * fpt))), block(256);
 #define DMR_SETUP(TET, FPT) k_setup_faces_lds<TET, FPT><<<grid, block, 0, st>>>(s.B, s.P, s.F, s.faces, vproj, gx, gy, r0, r1, \
                                 face_rect, key_depth, max_depth, tiles_touched, tile_count)
-    if (tet) { if (fpt == 1) DMR_SETUP(true, 1); else DMR_SETUP(true, BIN_FPT_MAX); }
-    else { if (fpt == 1) DMR_SETUP(false, 1); else DMR_SETUP(false, BIN_FPT_MAX); }
+    if (tet) { if (fpt == 1) DMR_SETUP(true, 1); else if (fpt == 2) DMR_SETUP(true, 2); else DMR_SETUP(true, 4); }
+    else { if (fpt == 1) DMR_SETUP(false, 1); else if (fpt == 2) DMR_SETUP(false, 2); else DMR_SETUP(false, 4); }
 #undef DMR_SETUP
 }
 
@@ -773,12 +773,12 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
     StageScope t(DMR_STAGE_SCATTER, st);
-    if (n < BIN_SMALL_MESH)
-        k_scatter_faces_lds<1><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(
-            s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
-    else
-        k_scatter_faces_lds<BIN_FPT_MAX><<<dim3((unsigned)((n + 256 * BIN_FPT_MAX - 1) / (256 * BIN_FPT_MAX))), dim3(256), 0, st>>>(
-            s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, tile_cursor, keys, capacity);
+    const int fpt = bin_fpt(n);
+    const dim3 grid((unsigned)((n + 256 * fpt - 1) / (256 * fpt))), block(256);
+#define DMR_SCATTER(FPT) k_scatter_faces_lds<FPT><<<grid, block, 0, st>>>(s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, \
+                                                                         tile_cursor, keys, capacity)
+    if (fpt == 1) DMR_SCATTER(1); else if (fpt == 2) DMR_SCATTER(2); else DMR_SCATTER(4);
+#undef DMR_SCATTER
 }
 
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
