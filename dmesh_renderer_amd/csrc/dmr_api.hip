@@ -437,8 +437,7 @@ int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     Dims d;
     if (check_scene(s, true, d)) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (s->P > 0) DMR_HIP(hipMemsetAsync(dL_dvcolor, 0, sizeof(float) * 3 * (size_t)s->P, st));
-    if (s->F > 0) DMR_HIP(hipMemsetAsync(dL_dfopacity, 0, sizeof(float) * (size_t)s->F, st));
+    dmr::launch_tet_zero_grads(dL_dvcolor, 3 * (int64_t)s->P, dL_dfopacity, (int64_t)s->F, st);
     if (s->P == 0 || s->F == 0) return 0;
     if (!image_buf || !face_buf) return fail("null scratch buffer");
     ImageState is; FaceState fs;

@@ -90,6 +90,7 @@ void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int 
                                 uint32_t capacity, TetImageState img, hipStream_t st);
 void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
                         float* out_color, float* out_depth, float* out_active, hipStream_t st);
+void launch_tet_zero_grads(float* dL_dvcolor, int64_t n_vcolor, float* dL_dfopacity, int64_t n_fopacity, hipStream_t st);
 void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dvcolor, float* dL_dfopacity,
                          hipStream_t st);
