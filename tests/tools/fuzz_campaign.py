@@ -13,36 +13,55 @@ from oracle import oracle as O
 from test_fuzz_gpu import _soup, _delaunay, NAMES
 
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=240); ap.add_argument("--seed0", type=int, default=1000)
+ap.add_argument("--big", action="store_true", help="fewer, larger tri cases: layered sheets up to ~400k faces, images up to 1600^2 (more than 8192 tiles), several views, random tile-row bands")
 a = ap.parse_args()
 O.build(); O.lib(); oracle = O; dev = th.device("cuda:0")
 t0 = time.time(); seed = a.seed0; ncase = 0; n_marginal = 0
 while time.time() - t0 < a.seconds:
     rng = np.random.RandomState(seed)
     B = int(rng.randint(1, 4)); H = int(rng.randint(17, 260)); W = int(rng.randint(17, 300))
-    tet = rng.rand() < 0.3
+    tet = rng.rand() < 0.3 and not a.big
+    rows = (0, 0)
+    if a.big:
+        H = int(rng.randint(200, 1600)); W = int(rng.randint(200, 1600))
+        if rng.rand() < 0.4:
+            gy = (H + 15) // 16; r0 = int(rng.randint(0, gy)); rows = (r0, int(rng.randint(r0 + 1, gy + 1)))
     gc, gd = upstream_grads(B, H, W)
     if not tet:
-        P = int(rng.randint(8, 600)); F = int(rng.randint(30, 3000))
-        d = _soup(seed, P, F, B, H, W)
-        if rng.rand() < 0.3: d["verts"] = d["verts"] * float(rng.uniform(0.05, 4.0))
-        sc = oracle.scene_from_module_inputs(d, H, W)
+        if a.big:
+            from dmesh_renderer_amd import scenes
+            L = int(rng.randint(1, 13)); n = int(rng.randint(20, 131))
+            d = scenes.layered_sheets(L, n, B, H, W, seed=seed, opacity=(0.05, float(rng.uniform(0.2, 0.95))))
+            P, F = d["verts"].shape[0], d["faces"].shape[0]
+            if rng.rand() < 0.5: d["verts"] = d["verts"] * float(rng.uniform(0.3, 3.0))
+        else:
+            P = int(rng.randint(8, 600)); F = int(rng.randint(30, 3000))
+            d = _soup(seed, P, F, B, H, W)
+            if rng.rand() < 0.3: d["verts"] = d["verts"] * float(rng.uniform(0.05, 4.0))
+        sc = oracle.scene_from_module_inputs(d, H, W, rows=rows)
         ocolor, odepth, ost = oracle.tri_forward(sc)
         args = c_args(d, dev)
-        out = _C.render_tris(*args, H, W); th.cuda.synchronize()
+        out = _C.render_tris(*args, H, W, rows=rows); th.cuda.synchronize()
         R, bufs = out[0], out[3:7]
-        ok = R == ost.num_rendered
         ex = lambda n, dt: _C.export(n, args, False, R, bufs, H, W, dt).cpu().numpy()
-        ok = ok and np.array_equal(ex("face_list", th.int32).view(np.uint32), ost.get("values"))
-        ok = ok and np.array_equal(ex("n_contrib", th.int32).view(np.uint32), ost.get("n_contrib"))
+        nc_g, nc_o = ex("n_contrib", th.int32).view(np.uint32).reshape(B, H, W), ost.get("n_contrib").reshape(B, H, W)
+        if rows != (0, 0):  # only the band's pixel rows are defined
+            y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
+            nc_g, nc_o = nc_g[:, y0:y1], nc_o[:, y0:y1]
+        checks = {"R": R == ost.num_rendered,
+                  "face_list": np.array_equal(ex("face_list", th.int32).view(np.uint32), ost.get("values")),
+                  "n_contrib": np.array_equal(nc_g, nc_o)}
+        ok = all(checks.values())
+        if not ok: print("   mismatch:", checks, "oracle R", ost.num_rendered, flush=True)
         fin = np.isfinite(ocolor).all(axis=1, keepdims=True)
         ferr = float(np.abs(np.where(fin, out[1].cpu().numpy() - ocolor, 0.0)).max())
         og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
-        g = _C.render_tris_backward(*args, gc.to(dev), gd.to(dev), R, *bufs); th.cuda.synchronize()
+        g = _C.render_tris_backward(*args, gc.to(dev), gd.to(dev), R, *bufs, rows=rows); th.cuda.synchronize()
         gerr = 0.0
         for got, k in zip(g, NAMES):
             x, r = got.cpu().numpy(), og[k]; f = np.isfinite(r)
             gerr = max(gerr, rel_err(np.where(f, x, 0.0), np.where(f, r, 0.0)))
-        desc = f"tri seed {seed} B {B} H {H} W {W} P {P} F {F} R {R}"
+        desc = f"tri seed {seed} B {B} H {H} W {W} P {P} F {F} R {R} rows {rows}"
     else:
         npts = int(rng.randint(20, 500))
         d = _delaunay(seed, npts, B, H, W)
