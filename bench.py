@@ -186,13 +186,18 @@ def main():
         from oracle import oracle as O  # checker / reported baseline only
         O.build()
         sc = O.scene_from_module_inputs(d, H, W)
-        t1 = time.perf_counter()
-        ocolor, odepth, ost = O.tri_forward(sc)
-        og = O.tri_backward(sc, ost, gc_cpu.numpy(), gd_cpu.numpy())
-        cdt = time.perf_counter() - t1
+        reps = 3 if a.config in ("C1", "C2", "C3", "C4") else 1  # the first pass also pays page faults and thread start-up
+        times = []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            ocolor, odepth, ost = O.tri_forward(sc)
+            og = O.tri_backward(sc, ost, gc_cpu.numpy(), gd_cpu.numpy())
+            times.append(time.perf_counter() - t1)
+        cdt = sorted(times)[len(times) // 2]
         cores = int(O.lib().dmro_num_threads())
         cpu_baseline = {"value": round(B * W * H / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-                        "sample": f"1 fwd+bwd of the full {a.config} workload ({cdt:.1f} s, OpenMP {cores} threads)"}
+                        "sample": f"median of {reps} fwd+bwd passes over the full {a.config} workload ({cdt:.2f} s each, "
+                                  f"{sum(times):.1f} s in all, OpenMP {cores} threads)"}
         parity["fwd_max_abs_err"] = float(max(np.abs(o[1].cpu().numpy() - ocolor).max(), np.abs(o[2].cpu().numpy() - odepth).max()))
         parity["grad_max_abs_err"] = float(max(rel_err(t.cpu().numpy(), og[k]) for t, k in
                                                zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense"))))
