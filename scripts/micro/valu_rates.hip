@@ -1,5 +1,5 @@
 // Micro-benchmark: VALU issue rates on gfx950 that decide how the hit-parallel backward should be written:
-// plain v_fma_f32, packed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, DPP forms (v_fmac_f32_dpp, v_add_f32_dpp,
+// plain v_fma_f32, 32/64-bit integer compare + add-with-carry (the rank sort's inner loop), packed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, DPP forms (v_fmac_f32_dpp, v_add_f32_dpp,
 // v_cndmask_b32_dpp + v_add_f32) and v_rcp_f32.  Reports SIMD cycles per wave-instruction with the SIMDs full.
 // hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip && ./valu_rates
 #include <hip/hip_runtime.h>
@@ -15,6 +15,8 @@
 #define CNDADD(i) "v_cndmask_b32_dpp %[t], %[a" #i "], %[c], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_f32 %[a" #i "], %[a" #i "], %[t]\n\t"
 #define RCP(i) "v_rcp_f32 %[a" #i "], %[a" #i "]\n\t"
 #define MADI24(i) "v_mad_i32_i24 %[a" #i "], %[a" #i "], %[m], %[c]\n\t"
+#define CMPU64(i) "v_cmp_lt_u64 vcc, %[p" #i "], %[pm]\n\tv_addc_co_u32 %[a" #i "], vcc, 0, %[a" #i "], vcc\n\t"
+#define CMPU32(i) "v_cmp_lt_u32 vcc, %[a" #i "], %[m]\n\tv_addc_co_u32 %[a" #i "], vcc, 0, %[a" #i "], vcc\n\t"
 
 #define A_OPS [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]), [a6] "+v"(a[6]), [a7] "+v"(a[7])
 #define P_OPS [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7])
@@ -37,6 +39,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
         else if (MODE == 6) asm volatile(REP8(CNDADD) REP8(CNDADD) : [t] "+v"(t), A_OPS : [c] "v"(c) : "vcc");
         else if (MODE == 7) asm volatile(REP8(RCP) REP8(RCP) : A_OPS :);
         else if (MODE == 8) asm volatile(REP8(MADI24) REP8(MADI24) : A_OPS : [m] "v"(m), [c] "v"(c));
+        else if (MODE == 9) asm volatile(REP8(CMPU64) REP8(CMPU64) : A_OPS : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]), [pm] "v"(pm) : "vcc");
+        else if (MODE == 10) asm volatile(REP8(CMPU32) REP8(CMPU32) : A_OPS : [m] "v"(m) : "vcc");
     }
     float s = t;
     for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
@@ -69,5 +73,7 @@ int main() {
     run<6>("v_cndmask_b32_dpp + v_add_f32 (pair = 2)", 32);
     run<7>("v_rcp_f32", 16);
     run<8>("v_mad_i32_i24", 16);
+    run<9>("v_cmp_lt_u64 + v_addc_co_u32 (pair = 2)", 32);
+    run<10>("v_cmp_lt_u32 + v_addc_co_u32 (pair = 2)", 32);
     return 0;
 }
