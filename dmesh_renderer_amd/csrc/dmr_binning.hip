@@ -321,16 +321,15 @@ k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face
 constexpr int ORDER_BUCKETS = 64;
 __device__ __forceinline__ int order_bucket(uint32_t n) { return ORDER_BUCKETS - 1 - (int)min(n >> 4, (uint32_t)(ORDER_BUCKETS - 1)); }
 // Neighbouring tiles have lists of similar length, so the lanes of a wave mostly want the SAME bucket, and same-address
-// LDS atomics retire one lane at a time (scripts/micro/lds_atomics.hip): 16 waves x 8 tiles x 64 lanes in a row, twice,
-// were 8 of k_scan_tiles' 18 us.  Every bucket therefore has ORDER_COPIES counters, picked by lane: at most four lanes
-// of a wave meet on one.  The order inside a bucket is arbitrary anyway.
+// LDS atomics retire one lane at a time (scripts/micro/lds_atomics.hip).  Every bucket therefore has ORDER_COPIES
+// counters, picked by lane: at most four lanes of a wave meet on one.  The order inside a bucket is arbitrary anyway.
+// (Measured: on its own this changed nothing at C4 -- 16.4 us before and after; the kernel's time was its uncoalesced
+// global accesses, see the slab below.  Kept: it bounds the worst case of a frame whose busy tiles share one bucket.)
 constexpr int ORDER_COPIES = 16;
 constexpr int ORDER_CELLS = ORDER_BUCKETS * ORDER_COPIES;  // + 1 cell for the empty tiles, behind all the others
 __device__ __forceinline__ int order_cell(uint32_t n, int lane) { return order_bucket(n) * ORDER_COPIES + (lane & (ORDER_COPIES - 1)); }
 
-// Both scans are one 1024-thread workgroup (n = B * tiles is small, C4: 8160).  Their time is the chain of
-// dependent global-memory round trips, so a thread fetches its items SCAN_BATCH at a time with independent loads
-// (the first version loaded one item per loop iteration, twice: 16 round trips, 14-17 us).
+// Both scans are one 1024-thread workgroup up to SCAN_SLAB tiles (C4: 8160), SCAN_BATCH tiles per thread.
 constexpr int SCAN_BATCH = 8;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, int tid, uint32_t* wave_sum /*[17]*/) {
