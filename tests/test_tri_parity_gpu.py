@@ -268,3 +268,23 @@ def test_shape_errors(hip_device):
     cpu = c_args(d, None)
     with pytest.raises(RuntimeError, match="no CPU path"):
         _C.render_tris(*cpu, 32, 32)
+
+
+def test_empty_band_renders_nothing(oracle, hip_device):
+    """A rank whose band is empty (balanced_bands can hand one out when a single tile row holds more than 1/world of
+    the work): rows=(r, r) with r > 0 renders nothing -- zero image, zero gradients, num_rendered 0 -- and a band
+    clamped away beyond the last row behaves the same."""
+    from dmesh_renderer_amd import _C
+    d, B, H, W = _make("ragged")
+    args = c_args(d, hip_device)
+    gc, gd = upstream_grads(B, H, W)
+    gy = (H + 15) // 16
+    for rows in ((3, 3), (gy, gy + 4)):
+        out = _C.render_tris(*args, H, W, rows=rows)
+        th.cuda.synchronize()
+        assert out[0] == 0
+        assert float(out[1].abs().max()) == 0.0 and float(out[2].abs().max()) == 0.0
+        g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7], rows=rows)
+        th.cuda.synchronize()
+        for t in g:
+            assert float(t.abs().max()) == 0.0
