@@ -356,7 +356,12 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
 // integer LDS atomics (0.146 ms); counting during rasterisation removed the passes, the pool and 4 of the ~9
 // barriers per chunk.
 // ---------------------------------------------------------------------------
-constexpr uint32_t HIT_SKIPPED = 0xffffffffu;  // HitRecord.pixel of a covered pair the forward skipped (denom == 0)
+// Bit 31 of HitRecord.pixel (pixel indices fit 31 bits, check_scene): a covered pair the forward skipped (denom == 0,
+// forward.cu:429-430).  Its record stays a member of its list entry's run of records -- same key in the hit-parallel
+// kernel's segmented scan, all sums zero -- because that scan assumes equal keys are contiguous: a record with a key of
+// its own in the middle of a run splits it, and the sum of the first part was staged twice (found by
+// tests/tools/fuzz_campaign.py: a sliver face whose denom is 0 at some pixels only).
+constexpr uint32_t HIT_SKIPPED = 0x80000000u;
 
 // rasterize_faces of the forward plus: only list positions below the pixel's n_contrib (s_lim = that bound relative
 // to the chunk start) get their bit, and the face's blended-pixel count goes to s_fcnt.
@@ -529,7 +534,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
             const V3 Pv = cross(rd, E2);
             const float denom = dot(Pv, E1);
             if (denom == 0.0f) {  // "edge case": skipped entirely (backward.cu:215-216); its slot says so
-                hr.pixel = HIT_SKIPPED; hr.T = 0.f; hr.dL_dalpha = 0.f;
+                hr.pixel = pixel | HIT_SKIPPED; hr.T = 0.f; hr.dL_dalpha = 0.f;
                 if (slot < capacity) hits[slot] = hr;
                 continue;
             }
@@ -713,18 +718,22 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         const uint32_t hi_idx = base + lane;
         HitRecord hr; hr.entry = 0u; hr.pixel = HIT_SKIPPED; hr.T = 0.f; hr.dL_dalpha = 0.f;
         if (hi_idx < nhits) hr = hits[hi_idx];
-        const bool valid = hr.pixel != HIT_SKIPPED;  // past the end, or a covered pair the forward skipped (denom == 0)
+        const bool valid = hi_idx < nhits;                    // lanes past the end: no record, unique keys
+        const bool skipped = (hr.pixel & HIT_SKIPPED) != 0u;  // member of its entry's run, contributes nothing
+        hr.pixel &= ~HIT_SKIPPED;
         int k = -1 - lane;  // invalid lanes: unique keys
         int v0 = 0, v1 = 0, v2 = 0, face = 0, b = 0;
         float g[NACC];
 #pragma unroll
         for (int c = 0; c < NACC; c++) g[c] = 0.f;
-        if (valid) {
-            using namespace fm;
+        if (valid) {  // key and row ids: a skipped pair at the end of its run still carries the run's sums to the tables
             k = (int)hr.entry;
             face = (int)p.face_list[hr.entry];
             b = (int)(hr.pixel / (uint32_t)HW);
             v0 = p.faces[3 * face]; v1 = p.faces[3 * face + 1]; v2 = p.faces[3 * face + 2];
+        }
+        if (valid && !skipped) {
+            using namespace fm;
             const float4 pr0 = pixrec[2 * (int64_t)hr.pixel], pr1 = pixrec[2 * (int64_t)hr.pixel + 1];
             const float alpha = p.faces_opacity[face], intense = p.faces_intense[(int64_t)b * p.F + face];
             const F3 cc0 = load3(p.verts_color, v0), cc1 = load3(p.verts_color, v1), cc2 = load3(p.verts_color, v2);

@@ -147,3 +147,28 @@ def test_changing_shapes_and_streams(oracle, hip_device):
         assert np.abs(out[1].cpu().numpy() - ocolor).max() <= 1e-5, it
         for got, k in zip(g, NAMES):
             assert rel_err(got.cpu().numpy(), og[k]) <= 1e-4, (it, k)
+
+
+def test_skipped_pair_inside_a_run_of_records(oracle, hip_device):
+    """Case 21192 of tests/tools/fuzz_campaign.py: a sliver face (two vertices 0.01 apart) is first in a tile list and
+    its denom is exactly 0 at some of its pixels only, so a skipped pair sits in the middle of the face's run of hit
+    records.  The hit-parallel backward once gave that record a scan key of its own, which split the run and staged the
+    sum of its first part twice (gradients of that face and its vertices off by a few percent)."""
+    from dmesh_renderer_amd import _C
+    rng = np.random.RandomState(21192)
+    B = int(rng.randint(1, 4)); H = int(rng.randint(17, 260)); W = int(rng.randint(17, 300)); rng.rand()
+    P = int(rng.randint(8, 600)); F = int(rng.randint(30, 3000))
+    assert (B, H, W, P, F) == (1, 130, 259, 410, 1755)
+    d = _soup(21192, P, F, B, H, W)
+    if rng.rand() < 0.3:
+        d["verts"] = d["verts"] * float(rng.uniform(0.05, 4.0))
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    ocolor, odepth, ost = oracle.tri_forward(sc)
+    args = c_args(d, hip_device)
+    out = _C.render_tris(*args, H, W)
+    assert out[0] == ost.num_rendered
+    gc, gd = upstream_grads(B, H, W)
+    og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+    g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7])
+    for got, k in zip(g, NAMES):
+        assert rel_err(got.cpu().numpy(), og[k]) <= 1e-4, k
