@@ -826,7 +826,7 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
                 atomicAdd(rf, g[21]); atomicAdd(rf + 1, g[22]);
 #pragma unroll
                 for (int c = 0; c < NACC; c++) g[c] = 0.f;
-                k = -1 - lane;
+                // (k stays the entry: like a skipped pair, the lane remains a member of its run with zero sums)
             }
         }
         // segmented inclusive scan over the wave (hits of one entry are consecutive lanes): four row-local
