@@ -6,7 +6,8 @@
 A step = one forward + one backward of the hot path (`_C.render_tris` + `_C.render_tris_backward`,
 i.e. the C ABI of libdmesh_renderer_hip.so) over one synthetic "layered sheets" scene (C4:
 16 sheets x 126^2 vertices = 500 000 triangles, one 1920x1080 view), inputs resident in HBM.
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the image is sharded by
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL) -- started by a launcher (torchrun sets
+WORLD_SIZE) or, when there is none, by this script itself (launch_ranks: N fresh child processes); the image is sharded by
 work-balanced bands of tile rows, every rank renders and back-propagates its band, and the five
 gradient tensors are summed with ONE all-reduce over a flattened fp32 buffer (strong scaling).
 
@@ -44,19 +45,90 @@ def parse():
     ap.add_argument("--config", default="C4", help="scene config (C1, C2, C4, C5); the metric is quoted on C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing table to stderr")
+    ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous only (gloo, no GPU): prints n_gpus")
     return ap.parse_args()
+
+
+def launch_ranks(n: int, argv, script=None, timeout_s: float = 3000.0) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, rendezvous on 127.0.0.1) and wait for them.  Called before anything in this
+    process has touched the GPU (no torch.cuda.is_available(), no HIP call): the children are new processes, this
+    one never re-executes itself and never initialises the device.  Returns the exit code for the parent: 0 only if
+    every rank exited 0; the first failing rank takes the others down (they would hang in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
+    rc, t_end = 0, time.time() + timeout_s
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+        if (rc != 0 or time.time() > t_end) and live:
+            for p in live:  # exactly the PIDs started above
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(a, world: int, rank: int):
+    """--dry-run: the N-rank launch and rendezvous without a GPU (gloo on the CPU): every rank joins the process
+    group, the ranks are counted with one all-reduce and rank 0 prints {"n_gpus": N}.  tests/test_bench_launch_cpu.py."""
+    n = 1
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        t = th.ones(1, dtype=th.int64)
+        dist.all_reduce(t)
+        n = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": n, "world_size_env": world, "gpus_flag": a.gpus}), flush=True)
 
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    backend = os.environ.get("DMR_DIST_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # no launcher around us: become one.  Nothing above has initialised the GPU (device_count() does not).
+        if not a.dry_run and backend == "nccl" and th.cuda.device_count() < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} needs {a.gpus} HIP devices, found {th.cuda.device_count()} "
+                             "(DMR_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
+    if a.dry_run:
+        return dry_run(a, world, rank)
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     # DMR_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the sharded path on a 1-GPU box;
     # the driver's multi-GPU runs use nccl (= RCCL), one rank per GPU
-    backend = os.environ.get("DMR_DIST_BACKEND", "nccl")
+    if backend == "nccl" and th.cuda.device_count() < world and world > 1:
+        raise SystemExit(f"{world} ranks need {world} HIP devices, found {th.cuda.device_count()}")
     local_rank = local_rank % max(1, th.cuda.device_count()) if backend != "nccl" else local_rank
     th.cuda.set_device(local_rank)
     dev = th.device("cuda", local_rank)

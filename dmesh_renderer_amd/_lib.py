@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdmesh_renderer_hip.so")
+# DMR_LIBRARY=<path>: load another build of the same C ABI (the ablation build of build.py --ablation, a tuning build)
+LIB_PATH = os.environ.get("DMR_LIBRARY") or os.path.join(HERE, "libdmesh_renderer_hip.so")
 ABI_VERSION = 2
 
 BUF_POINT, BUF_FACE, BUF_BINNING, BUF_IMAGE, BUF_WORK = range(5)

@@ -10,6 +10,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing ablations (scripts/prof_ablate.sh) and the forced-fallback switch of tests/test_fallback_gpu.py exist only in
+// the ABLATION build (`python -m dmesh_renderer_amd.build --ablation`: -DDMR_ABLATION, a separate
+// libdmesh_renderer_hip_ablation.so that reads the DMR_ABLATE environment variable).  The product library has no
+// such switch: DMR_DBG folds to false, the kernels' parameter blocks have no debug field, nothing calls getenv.
+#ifdef DMR_ABLATION
+#define DMR_DBG(p, bits) (((p).dbg & (bits)) != 0)
+#else
+#define DMR_DBG(p, bits) false
+#endif
+
 namespace dmr {
 
 constexpr int TILE = 16;            // cuda_*/config.h:5-6 (BLOCK_X = BLOCK_Y = 16)

@@ -29,7 +29,10 @@ struct alignas(16) TetColRec { float c0[3], c1[3], c2[3]; int v0, v1, v2; float 
 static_assert(sizeof(TetColRec) == 64, "TetColRec");
 
 struct TetParams {
-    int B, P, F, W, H, gx, gy, r0, dbg;
+    int B, P, F, W, H, gx, gy, r0;
+#ifdef DMR_ABLATION
+    int dbg;  // DMR_ABLATE bits (ablation build only)
+#endif
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* mv; const float* proj; const float* inv_mv; const float* inv_proj;
     const float* faces_intense; const float* bg;
@@ -470,8 +473,8 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
                     g[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g[c]), 0x140, 0xF, 0xF, false));
             }
             const bool follower = hex ? (lane & 15) != 0 : (oct ? (lane & 7) != 0 : (quad && (lane & 3) != 0));
-            // (DMR_ABLATE bit 2048, tests only: odd faces are refused a slot, which exercises the direct-atomic fallback)
-            const int slot = follower ? -2 : (((p.dbg & 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face));
+            // (ablation build, DMR_ABLATE bit 2048, tests only: odd faces are refused a slot, which exercises the direct-atomic fallback)
+            const int slot = follower ? -2 : ((DMR_DBG(p, 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face));
             if (slot == -2) {
                 // this lane's values went out with the first lane of its quad / octet / row
             } else if (slot >= 0) {
@@ -510,7 +513,9 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
 static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImageState img) {
     TetParams p;
     p.B = s.B; p.P = s.P; p.F = s.F; p.W = s.W; p.H = s.H; p.gx = gx; p.gy = gy; p.r0 = r0;
-    { static const int dbg = getenv("DMR_ABLATE") ? atoi(getenv("DMR_ABLATE")) : 0; p.dbg = dbg; }  // tests / timing ablations only
+#ifdef DMR_ABLATION
+    { static const int dbg = getenv("DMR_ABLATE") ? atoi(getenv("DMR_ABLATE")) : 0; p.dbg = dbg; }  // ablation build only
+#endif
     p.verts = s.verts; p.faces = s.faces; p.verts_color = s.verts_color; p.faces_opacity = s.faces_opacity;
     p.mv = s.mv_mats; p.proj = s.proj_mats; p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats;
     p.faces_intense = s.faces_intense; p.bg = s.background;

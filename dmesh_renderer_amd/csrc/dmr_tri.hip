@@ -61,7 +61,10 @@ struct alignas(16) ShadeRec {
 static_assert(sizeof(ShadeRec) == 112, "ShadeRec");
 
 struct TriParams {
-    int B, P, F, W, H, gx, gy, r0, r1, dbg;
+    int B, P, F, W, H, gx, gy, r0, r1;
+#ifdef DMR_ABLATION
+    int dbg;  // DMR_ABLATE bits (ablation build only)
+#endif
     uint32_t list_capacity;  // entries face_list holds (< R only while a size guess is being refuted)
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* inv_mv; const float* inv_proj; const float* faces_intense; const float* bg;
@@ -223,7 +226,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         face_next = base + 2 * CHUNK + sj < end ? (int)p.face_list[base + 2 * CHUNK + sj] : -1;
         *reinterpret_cast<uint4*>(&s_pm[tid][0]) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
-        if (!(p.dbg & 16)) rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // A
+        if (!DMR_DBG(p, 16)) rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // A
         __syncthreads();
         uint32_t m[WORDS];
         {
@@ -231,7 +234,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
             m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
         }
 #pragma unroll
-        for (int w = 0; w < WORDS; w++) if (done || (p.dbg & 8)) m[w] = 0;
+        for (int w = 0; w < WORDS; w++) if (done || DMR_DBG(p, 8)) m[w] = 0;
         if (__all(done)) continue;  // wave-uniform
         while (true) {
             int w = -1; uint32_t mw = 0;
@@ -493,7 +496,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         for (int w = 0; w < WORDS; w++) s_pm[pl][w] = 0u;
         s_lim[pl] = last_contributor > lo ? min(last_contributor - lo, (uint32_t)CHUNK) : 0u;
         __syncthreads();
-        if (!(p.dbg & 4)) rasterize_faces_counted<CHUNK>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // ---- A
+        if (!DMR_DBG(p, 4)) rasterize_faces_counted<CHUNK>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // ---- A
         __syncthreads();
         if (wave == 0) {  // ---- S: lane l scans counters [l * PER, (l + 1) * PER)
             constexpr int PER = CHUNK / 64;
@@ -666,8 +669,8 @@ __device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L
         const int sb = __float_as_int(row[27]);
         if (w < 3) {
             const uint32_t rid = (uint32_t)sb * (uint32_t)p.P + (uint32_t)__float_as_int(row[23 + w]);
-            // (DMR_ABLATE bit 2048, tests only: odd rows are refused a slot, which exercises the direct-atomic fallback)
-            const int slot = ((p.dbg & 2048) && (rid & 1u)) ? -1 : tab_find<VTAB>(L.vkey, rid);
+            // (ablation build, DMR_ABLATE bit 2048, tests only: odd rows are refused a slot, which exercises the direct-atomic fallback)
+            const int slot = (DMR_DBG(p, 2048) && (rid & 1u)) ? -1 : tab_find<VTAB>(L.vkey, rid);
             float v[7];
 #pragma unroll
             for (int c = 0; c < 3; c++) { v[c] = row[3 * w + c]; v[3 + c] = row[9 + 3 * w + c]; }
@@ -681,7 +684,7 @@ __device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L
             }
         } else {
             const uint32_t rid = (uint32_t)sb * (uint32_t)p.F + (uint32_t)__float_as_int(row[26]);
-            const int slot = ((p.dbg & 2048) && (rid & 1u)) ? -1 : tab_find<FTAB>(L.fkey, rid);
+            const int slot = (DMR_DBG(p, 2048) && (rid & 1u)) ? -1 : tab_find<FTAB>(L.fkey, rid);
             if (slot >= 0) { atomicAdd(&L.fval[slot][0], (double)row[21]); atomicAdd(&L.fval[slot][1], (double)row[22]); }
             else { atomicAdd(&frow[(int64_t)rid * FROW], row[21]); atomicAdd(&frow[(int64_t)rid * FROW + 1], row[22]); }
         }
@@ -853,12 +856,12 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
                 st[23] = __int_as_float(v0); st[24] = __int_as_float(v1); st[25] = __int_as_float(v2);
                 st[26] = __int_as_float(face); st[27] = __int_as_float(b);
             }
-            if (!(p.dbg & 512)) accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
+            if (!DMR_DBG(p, 512)) accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
         }
     }
     // every row of the tables goes out once: 8 lanes per vertex row (7 used), 2 lanes per face row
     __syncthreads();
-    if (p.dbg & 1024) return;
+    if (DMR_DBG(p, 1024)) return;
     for (int s0 = 0; s0 < VTAB; s0 += 32) {
         const int slot = s0 + (tid >> 3), comp = tid & 7;
         const uint32_t rid = L.vkey[slot];
@@ -905,7 +908,9 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img) {
     TriParams p;
     p.B = s.B; p.P = s.P; p.F = s.F; p.W = s.W; p.H = s.H; p.gx = gx; p.gy = gy; p.r0 = r0; p.r1 = r1;
-    { static const int dbg = getenv("DMR_ABLATE") ? atoi(getenv("DMR_ABLATE")) : 0; p.dbg = dbg; }  // timing ablations only
+#ifdef DMR_ABLATION
+    { static const int dbg = getenv("DMR_ABLATE") ? atoi(getenv("DMR_ABLATE")) : 0; p.dbg = dbg; }  // ablation build only
+#endif
     p.verts = s.verts; p.faces = s.faces; p.verts_color = s.verts_color; p.faces_opacity = s.faces_opacity;
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;

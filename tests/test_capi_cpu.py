@@ -68,3 +68,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "dmr_oracle" not in txt, f
+
+
+def test_product_library_has_no_ablation_switch():
+    """The DMR_ABLATE switches (timing ablations, forced fallback) are compiled out of the product library: no getenv
+    import at all; the ablation build (build.py --ablation) is a separate file that has it."""
+    import subprocess
+    from dmesh_renderer_amd import build
+    prod, abl = build.build(), build.build(ablation=True)
+    syms = lambda lib: subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms(prod)
+    assert "getenv" in syms(abl)
+    for f in ("dmr_tri.hip", "dmr_tet.hip", "dmr_binning.hip", "dmr_api.hip"):
+        src = open(os.path.join(ROOT, "dmesh_renderer_amd", "csrc", f)).read()
+        for m in re.finditer(r"getenv", src):
+            before = src[:m.start()]
+            assert before.rfind("#ifdef DMR_ABLATION") > before.rfind("#endif"), f"{f}: getenv outside DMR_ABLATION"

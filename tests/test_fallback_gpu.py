@@ -1,5 +1,6 @@
 """The aggregation tables of the backward kernels (LDS hash tables in front of the global atomics) fall back to
-direct atomics when a row finds no slot.  Real scenes rarely get there, so a child process runs the library with
+direct atomics when a row finds no slot.  Real scenes rarely get there, so a child process runs the ABLATION build of
+the library (build.py --ablation; the product library has no such switch and ignores the variable) with
 DMR_ABLATE=2048 -- rows with an odd id are refused a slot -- and checks the gradients against the oracle."""
 import os
 import subprocess
@@ -45,7 +46,9 @@ print("fallback ok")
 
 
 def test_direct_atomic_fallbacks(hip_device):
-    env = dict(os.environ, DMR_ABLATE="2048")
+    from dmesh_renderer_amd import build
+    lib = build.build(ablation=True)  # prebuilt by __graft_entry__.build(); compiled here only if missing or stale
+    env = dict(os.environ, DMR_ABLATE="2048", DMR_LIBRARY=lib)
     r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr

@@ -16,3 +16,20 @@ def test_two_ranks_match_full_render(hip_device):
            "--master-port", "29531", os.path.join(HERE, "sharded_child.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_gpus_2_rehearsal(hip_device):
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself: here both
+    share the one GPU over gloo; the line must say n_gpus 2 and carry the sharded parallelism."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DMR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C2", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0
+    assert "x2" in j["config"]["parallelism"]
