@@ -285,8 +285,11 @@ def render_tets(background, verts, faces, verts_color, faces_opacity, mv_mats, p
 
 def render_tets_backward(background, verts, faces, verts_color, faces_opacity, mv_mats, proj_mats, inv_mv_mats,
                          inv_proj_mats, verts_depth, faces_intense, tets, face_tets, tet_faces, grad_color,
-                         grad_depth, pointBuffer, faceBuffer, binningBuffer, imageBuffer, rows=(0, 0)):
-    """-> (dL_dverts_color [P,3], dL_dfaces_opacity [F])"""
+                         grad_depth, pointBuffer, faceBuffer, binningBuffer, imageBuffer, rows=(0, 0), flat_out=None):
+    """-> (dL_dverts_color [P,3], dL_dfaces_opacity [F])
+
+    Extension for the sharded path: `flat_out`, a float32 HIP tensor of 3P + F elements, receives both gradients back
+    to back (the layout of the one all-reduce in sharding.py); the returned tensors are views into it."""
     lib = _lib.load()
     dev = _device_of(verts)
     H, W = grad_color.size(2), grad_color.size(3)  # render.cu:371-372
@@ -295,8 +298,14 @@ def render_tets_backward(background, verts, faces, verts_color, faces_opacity, m
                      inv_proj_mats, verts_depth, faces_intense, H, W,
                      tets=tets, face_tets=face_tets, tet_faces=tet_faces, seed=0, rows=rows)
         gc, gd = _f32(grad_color, "grad_color"), _f32(grad_depth, "grad_depth")
-        g_vcolor = th.empty((call.P, 3), dtype=th.float32, device=dev)
-        g_fop = th.empty((call.F,), dtype=th.float32, device=dev)
+        if flat_out is None:
+            g_vcolor = th.empty((call.P, 3), dtype=th.float32, device=dev)
+            g_fop = th.empty((call.F,), dtype=th.float32, device=dev)
+        else:
+            n = 3 * call.P + call.F
+            if flat_out.dtype != th.float32 or flat_out.device != dev or not flat_out.is_contiguous() or flat_out.numel() != n:
+                _err(f"flat_out must be a contiguous float32 tensor of {n} elements on {dev}")
+            g_vcolor, g_fop = flat_out.view(-1)[:3 * call.P].view(call.P, 3), flat_out.view(-1)[3 * call.P:]
         bufs = [b.contiguous() for b in (pointBuffer, faceBuffer, binningBuffer, imageBuffer)]
         rc = lib.dmr_tet_backward(C.byref(call.scene), _ptr(gc), _ptr(gd), *[_ptr(b) for b in bufs],
                                   _ptr(g_vcolor), _ptr(g_fop), call.alloc, None, call.stream())

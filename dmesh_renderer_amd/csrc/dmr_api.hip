@@ -187,12 +187,14 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
     int* host_R = reinterpret_cast<int*>(sr->slot);
 
-    auto front = [&]() -> int {
+    // write_host: the scan also stores R in the pinned slot.  Not on the redo pass: R is known by then, and a late
+    // store could land in the slot after this call has returned and a later call (another stream) reuses it.
+    auto front = [&](bool write_host) -> int {
         // (tile_count | tile_hits are contiguous: zeroed by k_project_verts, a slice per block)
         dmr::launch_project_verts(*s, ps.vproj, is.mats, is.tile_count, (size_t)(is.scan_tmp + dmr::SCAN_TMP_BUCKETS - is.tile_count), st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
-        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, is.tile_order, is.scan_tmp, st);
+        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, write_host ? host_R : nullptr, is.tile_order, is.scan_tmp, st);
         return 0;
     };
     auto rest = [&](uint64_t capacity) -> int {
@@ -217,7 +219,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (it != g_size_cache.end() && it->second.rendered_per_face > 0.0)
             guess = std::min<uint64_t>(padded((uint64_t)(it->second.rendered_per_face * (double)d.BF)), 0x7fffffffu);
     }
-    if (front()) return 1;
+    if (front(true)) return 1;
     DMR_HIP(hipEventRecord(sr->ev, st));
     if (guess && rest(guess)) return 1;
     DMR_HIP(hipEventSynchronize(sr->ev));  // the forward's one host wait (rasterizer_impl.cu:287-292): 4 bytes
@@ -228,7 +230,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (rest((uint64_t)R)) return 1;
     } else if ((uint64_t)R > guess) {  // the guess was too small: redo binning + render with the exact size
         DMR_HIP(hipStreamSynchronize(st));
-        if (front() || rest((uint64_t)R)) return 1;
+        if (front(false) || rest((uint64_t)R)) return 1;
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);

@@ -433,7 +433,7 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) { const int i = j * 1024 + tid; if (i < n) tile_order[i] = slab[i]; }
     // host_num_rendered: pinned host memory, read by the host after the event recorded behind this kernel
-    if (tid == 0) { tile_offset[n] = total; *num_rendered = (int)total; *host_num_rendered = (int)total; }
+    if (tid == 0) { tile_offset[n] = total; *num_rendered = (int)total; if (host_num_rendered) *host_num_rendered = (int)total; }
 }
 
 // ---- the same for many tiles (B * tiles > SCAN_SINGLE_MAX: several views at 1080p, 4096^2 images): one workgroup
@@ -489,7 +489,7 @@ k_scan_tiles_blocks(int nblk, int n, uint32_t* __restrict__ blk_sum, uint32_t* _
     }
     if (tid == 0) {
         tile_offset[n] = (uint32_t)carry;
-        if (num_rendered) { *num_rendered = (int)carry; *host_num_rendered = (int)carry; }
+        if (num_rendered) { *num_rendered = (int)carry; if (host_num_rendered) *host_num_rendered = (int)carry; }
         if (total64) { *total64 = carry; *host_total64 = carry; }
     }
     if (bucket_count && tid < 128) {  // waves 0 and 1; only wave 0 holds buckets 0..63, the empty-tile bucket follows them

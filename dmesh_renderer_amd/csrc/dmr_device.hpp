@@ -224,14 +224,16 @@ __device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int
         e.bx[i] = (int32_t)(0u - 16u * cy[i]);
         e.by[i] = (int32_t)(16u * cx[i]);
     }
-    // Pixel box.  A pixel centre (16x+8, 16y+8) can only pass the three edge tests if it lies inside the
-    // closed box of the snapped vertices -- provided nothing wrapped: with every vertex within 2^15
-    // sub-pixels (2048 px) of the tile origin all products stay below 2^31.  Otherwise the whole tile.
+    // Pixel box.  A pixel centre (16x+8, 16y+8) can only pass the three edge tests if it lies inside the closed box of
+    // the snapped vertices -- provided no int32 product wrapped.  With every vertex within D = 2^14 sub-pixels (1024 px)
+    // of the tile's first pixel centre: |c| = |v_i - v_j| < 2D, |p - v| < D + 240 (the tile's other pixels), so
+    // |s| <= 2 * 2D * (D + 240) = 1.09e9 < 2^31 (at D = 2^15 it is 4.3e9: a triangle spanning ~4000 px around a tile
+    // could wrap and, in the reference, cover pixels outside its box).  Otherwise the whole tile is rasterised.
     const int32_t X[3] = {(int32_t)x1, (int32_t)x2, (int32_t)x3}, Y[3] = {(int32_t)y1, (int32_t)y2, (int32_t)y3};
     const int32_t ox = 16 * x0 + 8, oy = 16 * y0 + 8;  // centre of the tile's first pixel
     bool near = true;
 #pragma unroll
-    for (int i = 0; i < 3; i++) near = near && abs(X[i] - ox) < (1 << 15) && abs(Y[i] - oy) < (1 << 15) && abs(X[i]) < (1 << 29) && abs(Y[i]) < (1 << 29);
+    for (int i = 0; i < 3; i++) near = near && abs(X[i] - ox) < (1 << 14) && abs(Y[i] - oy) < (1 << 14) && abs(X[i]) < (1 << 29) && abs(Y[i]) < (1 << 29);
     e.x0 = 0; e.x1 = TILE - 1; e.y0 = 0; e.y1 = TILE - 1;
     if (near) {
         const int32_t minx = min(min(X[0], X[1]), X[2]) - ox, maxx = max(max(X[0], X[1]), X[2]) - ox;

@@ -221,7 +221,28 @@ def upstream_grads(B: int, H: int, W: int, seed: int = 1):
 
 
 def rel_err(got: np.ndarray, ref: np.ndarray) -> float:
-    """max-abs(got - ref) / max(1, max-abs(ref)): the gradient error of the metric."""
+    """NORMALISED error max-abs(got - ref) / max(1, max-abs(ref)): SURVEY 8(d)'s definition of the metric's gradient
+    error (a whole-tensor figure: entries much smaller than the largest one are only checked in absolute terms; see
+    max_abs_err for the plain difference and elementwise_close for a per-entry check)."""
     if ref.size == 0:
         return 0.0
     return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / max(1.0, float(np.abs(ref).max())))
+
+
+def max_abs_err(got: np.ndarray, ref: np.ndarray) -> float:
+    """max |got - ref|, not normalised."""
+    if ref.size == 0:
+        return 0.0
+    return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max())
+
+
+def elementwise_close(got: np.ndarray, ref: np.ndarray, rtol: float = 1e-3, atol_scale: float = 2e-6) -> bool:
+    """Per entry: |got - ref| <= atol + rtol * |ref| with atol = atol_scale * max(1, max-abs(ref)).  A gradient entry is
+    a sum of many signed per-pixel terms (float atomics in the reference, table sums here), so its absolute error
+    scales with the tensor, not with the entry; the rtol term makes every entry that stands out of that noise floor
+    agree to 0.1 %."""
+    if ref.size == 0:
+        return True
+    g, r = got.astype(np.float64), ref.astype(np.float64)
+    atol = atol_scale * max(1.0, float(np.abs(r).max()))
+    return bool((np.abs(g - r) <= atol + rtol * np.abs(r)).all())

@@ -42,6 +42,33 @@ for assemble in (True, False):
     for a, b, k in zip(g, full[2], names):
         e = scenes.rel_err(a.cpu().numpy(), b.cpu().numpy())
         assert e <= 1e-5, (k, e)
+
+# the tet renderer, same sharding (ShardedTetRenderer: bands, one all-gather of the images, ONE all-reduce over [3P | F])
+Ht = Wt = 160
+dt = scenes.kuhn_tets(5, B, Ht, Wt, seed=3)
+tt = {k: v.to(dev) for k, v in dt.items()}
+gct, gdt = scenes.upstream_grads(B, Ht, Wt)
+gct, gdt = gct.to(dev), gdt.to(dev)
+tsettings = dmr.TetRenderSettings(Ht, Wt, tt["bg"], 0)
+
+
+def run_tet(renderer):
+    vc = tt["verts_color"].clone().requires_grad_(True); fo = tt["faces_opacity"].clone().requires_grad_(True)
+    color, depth, active = renderer(tt["verts"], tt["faces"], vc, fo, tt["mv_mats"], tt["proj_mats"], tt["verts_depth"],
+                                    tt["faces_intense"], tt["tets"], tt["face_tets"], tt["tet_faces"])
+    th.autograd.backward([color, depth], [gct, gdt])
+    return color.detach(), depth.detach(), active, [vc.grad, fo.grad]
+
+
+tfull = run_tet(dmr.TetRenderer(tsettings))
+assert bool(tfull[2].any())
+sht = sharding.ShardedTetRenderer(tsettings, assemble=True)
+assert sht.world == 2 and sht.rows != (0, 0)
+c, z, a, g = run_tet(sht)
+assert th.equal(c, tfull[0]) and th.equal(z, tfull[1]) and th.equal(a, tfull[2]), "assembled tet image differs"
+for x, y, k in zip(g, tfull[3], ("verts_color", "faces_opacity")):
+    e = scenes.rel_err(x.cpu().numpy(), y.cpu().numpy())
+    assert e <= 1e-5, (k, e)
 dist.barrier()
 if rank == 0:
     print("sharded ok")

@@ -74,6 +74,55 @@ def test_two_rank_band_sharding(tmp_path, oracle):
         assert np.array_equal(r0[k], r1[k])
 
 
+def _tet_worker(rank, world, port, out_dir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dmesh_renderer_amd as dmr
+        from dmesh_renderer_amd import scenes, sharding
+        import oracle_C
+        H, W, B = 88, 72, 2
+        d = scenes.kuhn_tets(3, B, H, W, seed=2)
+        gc, gd = scenes.upstream_grads(B, H, W)
+        vc = d["verts_color"].clone().requires_grad_(True); fo = d["faces_opacity"].clone().requires_grad_(True)
+        r = sharding.ShardedTetRenderer(dmr.TetRenderSettings(H, W, d["bg"], 0), assemble=True, impl=oracle_C)
+        r.bands = [(0, 2), (2, sharding.tile_rows(H))]  # unequal bands: 2 and 4 tile rows
+        color, depth, active = r(d["verts"], d["faces"], vc, fo, d["mv_mats"], d["proj_mats"], d["verts_depth"],
+                                 d["faces_intense"], d["tets"], d["face_tets"], d["tet_faces"])
+        ((color * gc).sum() + (depth * gd).sum()).backward()
+        np.savez(os.path.join(out_dir, f"tet{rank}.npz"), color=color.detach().numpy(), depth=depth.detach().numpy(),
+                 active=active.numpy(), g_vc=vc.grad.numpy(), g_fo=fo.grad.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_tet_band_sharding(tmp_path, oracle):
+    """ShardedTetRenderer ("the tet path shards identically"): bands of the march, one all-gather of the
+    three images, ONE all-reduce over [3P | F] -- every rank ends with the unsharded result."""
+    world = 2
+    mp.spawn(_tet_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import oracle_C
+    from dmesh_renderer_amd import scenes
+    H, W, B = 88, 72, 2
+    d = scenes.kuhn_tets(3, B, H, W, seed=2)
+    gc, gd = scenes.upstream_grads(B, H, W)
+    args = scenes.c_args(d, tet=True)
+    full = oracle_C.render_tets(*args, H, W, 0)
+    gfull = oracle_C.render_tets_backward(*args, gc, gd, *full[3:7])
+    assert full[2].sum() > 0
+    for k in range(world):
+        r = np.load(tmp_path / f"tet{k}.npz")
+        assert np.array_equal(r["color"], full[0].numpy()) and np.array_equal(r["depth"], full[1].numpy())
+        assert np.array_equal(r["active"], full[2].numpy() > 0.5)
+        for key, g in (("g_vc", gfull[0]), ("g_fo", gfull[1])):
+            assert np.abs(r[key] - g.numpy()).max() <= 1e-5 * max(1.0, float(g.abs().max())), key
+
+
 def test_band_helpers():
     from dmesh_renderer_amd import sharding
     assert sharding.equal_bands(68, 8)[0] == (0, 8) and sharding.equal_bands(68, 8)[-1][1] == 68

@@ -36,6 +36,10 @@ CASES = {
     # triangles far larger than the image, vertices far off-screen and behind the camera (mirrored by
     # clamp_w, Q2): exercises whole-tile coverage, the non-"near" / 32-bit coverage paths and int32 wrap (Q7)
     "huge": (3, 4, 2, 96, 144, (0.1, 0.4)),
+    # four triangles spanning ~4000 px of a 4096^2 image (65 536 sub-pixel units): the int32 products of in_tri wrap
+    # (Q7) for tiles far from the vertices, so the per-tile pixel box may only be trusted near them (edge_setup's
+    # 2^14 bound); every one of the 65 536 tiles holds a short list
+    "span_4000": (2, 2, 1, 4096, 4096, (0.1, 0.4)),
 }
 
 
@@ -44,6 +48,8 @@ def _make(case):
     d = scenes.layered_sheets(L, n, B, H, W, seed=0, opacity=op)
     if case == "huge":
         d["verts"] = d["verts"] * th.tensor([40.0, 40.0, 3.0])
+    if case == "span_4000":
+        d["verts"] = d["verts"] * th.tensor([1.7, 1.7, 1.0])
     if case == "many_big":
         d["verts"] = d["verts"] * th.tensor([6.0, 6.0, 1.0])
     if case == "alpha_one":
