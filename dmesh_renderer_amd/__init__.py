@@ -16,7 +16,22 @@ from typing import NamedTuple, Tuple
 
 import torch as th
 
-from . import _C
+class _NotBuilt:
+    """Stands in for `_C` while the native pieces are missing, so that `dmesh_renderer_amd.build` itself stays
+    importable; any use of the renderer raises -- there is no CPU or Python fallback."""
+
+    def __init__(self, cause):
+        self._cause = cause
+
+    def __getattr__(self, name):
+        raise ImportError(f"dmesh_renderer_amd._C cannot be imported ({self._cause}). Build the native pieces first: "
+                          "`python -m dmesh_renderer_amd.build` (hipcc + g++, in-tree); there is no CPU or Python fallback.")
+
+
+try:
+    from . import _C  # the compiled binding (csrc/dmr_torch.cpp) over libdmesh_renderer_hip.so
+except ImportError as _e:  # not built yet, or its HIP library is missing / of another ABI version
+    _C = _NotBuilt(_e)
 
 __all__ = ["TriRenderSettings", "render_tri", "TriRenderer", "TetRenderSettings", "render_tet", "TetRenderer"]
 

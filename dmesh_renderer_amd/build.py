@@ -1,4 +1,8 @@
-"""Builds dmesh_renderer_amd/libdmesh_renderer_hip.so (gfx950 only) with hipcc, in-tree.
+"""Builds the two native pieces of the package, in-tree:
+
+  * libdmesh_renderer_hip.so -- the C ABI (include/dmesh_renderer_amd.h) and every gfx950 kernel, with hipcc;
+  * _C.<python ext suffix>   -- `dmesh_renderer_amd._C`, the compiled PyTorch-ROCm binding over that C ABI
+                                (csrc/dmr_torch.cpp: pybind11 + ATen, no kernels), with g++.
 
     python -m dmesh_renderer_amd.build [--force] [--ablation]
 
@@ -36,6 +40,57 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+def _glue_path() -> str:
+    import sysconfig
+    return os.path.join(HERE, "_C" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+GLUE_SOURCES = ["dmr_torch.cpp", os.path.join("..", "..", "include", "dmesh_renderer_amd.h")]
+
+
+def glue_stale() -> bool:
+    out = _glue_path()
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in GLUE_SOURCES) or os.path.getmtime(os.path.abspath(__file__)) > t
+
+
+def build_glue(force: bool = False, verbose: bool = False) -> str:
+    """dmesh_renderer_amd._C: host C++ only (shape checks, allocation through PyTorch's caching allocator, the current
+    HIP stream, raw-pointer hand-off to the C ABI, which it loads with dlopen)."""
+    out = _glue_path()
+    if not force and not glue_stale():
+        return out
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("g++ not found: the PyTorch binding cannot be built")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_C",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"]]
+    cmd += [os.path.join(CSRC, "dmr_torch.cpp"), "-o", out + ".tmp", "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
+            "-ltorch", "-ltorch_python", "-Wl,-rpath," + tlib, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    """Everything the package needs at import: the HIP library and the binding (nothing if both are up to date)."""
+    res = build(force=force, verbose=verbose), build_glue(force=force, verbose=verbose)
+    pkg = sys.modules.get(__package__ or "dmesh_renderer_amd")
+    if pkg is not None and type(getattr(pkg, "_C", None)).__name__ == "_NotBuilt":  # imported before it was built
+        import importlib
+        pkg._C = importlib.import_module(pkg.__name__ + "._C")
+    return res
+
+
 def stale(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
         return True
@@ -63,3 +118,5 @@ def build(force: bool = False, verbose: bool = False, ablation: bool = False) ->
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))
+    if "--ablation" not in sys.argv:
+        print(build_glue(force="--force" in sys.argv, verbose=True))

@@ -130,8 +130,9 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     return 0;
 }
 
-// pinned (coherent, device-visible) landing pad the scan kernels write the sizes to, and the event the host
-// waits on; one per host thread and device (an event belongs to the device it was created on)
+// pinned (coherent, device-visible) landing pad the scan kernels write the sizes to (forward: the int at byte 0,
+// backward: the 64-bit count at byte 8), and the event the host waits on; one per host thread and device (an event
+// belongs to the device it was created on)
 struct SizeRead { void* slot = nullptr; hipEvent_t ev = nullptr; };
 SizeRead* size_read() {
     thread_local std::map<int, SizeRead> per_device;
@@ -147,6 +148,28 @@ SizeRead* size_read() {
     return &sr;
 }
 
+// Sticky per-device overflow word of the asynchronous / captured calls (pinned host memory the scan kernels store 1
+// into when a scene outgrew the capacity a call was enqueued with); read by dmr_overflowed().  Created by the first
+// default (waiting) call on a device -- never inside a stream capture, where hipHostMalloc is not allowed.
+std::mutex g_overflow_mu;
+std::map<int, uint32_t*> g_overflow;
+uint32_t* overflow_word(int dev, bool create) {
+    std::lock_guard<std::mutex> lk(g_overflow_mu);
+    auto it = g_overflow.find(dev);
+    if (it != g_overflow.end()) return it->second;
+    if (!create) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return nullptr;
+    *reinterpret_cast<volatile uint32_t*>(p) = 0u;
+    return g_overflow[dev] = reinterpret_cast<uint32_t*>(p);
+}
+
+bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 // Speculative sizing.  The sizes of the binning buffer (R) and of the hit-record buffer are
 // only known on the device.  The reference stalls the pipeline on a device->host read before it can continue
 // (rasterizer_impl.cu:287-299).  Here the previous call with the same view configuration provides a capacity guess
@@ -155,14 +178,17 @@ SizeRead* size_read() {
 // pinned host memory, not on the stream, so the GPU keeps running.  Kernels clamp their writes to the capacity; if
 // the exact size turns out larger the affected stages are simply enqueued again with an exact buffer (first call,
 // or a scene that grew by more than 25 %).
-// The guess is keyed by the view configuration only and kept as RATIOS (list entries per face-view, hit records
-// per list entry): a mesh whose face count changes every iteration (DMesh re-tetrahedralises) still gets a guess,
-// and the cache stays a handful of entries.
+// The guess is keyed by the view configuration only and kept as RATIOS (list entries and hit records per (view, face)
+// pair): a mesh whose face count changes every iteration (DMesh re-tetrahedralises) still gets a guess, and the cache
+// stays a handful of entries.
+// Asynchronous calls (DMR_FLAG_ASYNC, or a stream that is being captured into a HIP graph) use the same estimate and
+// never wait: the size is not read back at all, the scan kernel compares it with the capacity on the device and sets
+// the sticky overflow word (dmr_overflowed).  That is what makes forward + backward capturable as one graph.
 struct SizeKey {
     int v[6];
     bool operator<(const SizeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
-struct SizeGuess { double rendered_per_face = 0.0, hits_per_rendered = 0.0; };
+struct SizeGuess { double rendered_per_face = 0.0, hits_per_face = 0.0; };
 std::mutex g_size_mu;
 std::map<SizeKey, SizeGuess> g_size_cache;
 SizeKey size_key(const dmr_scene* s, bool tet, const Dims& d) {
@@ -183,18 +209,20 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     carve_point(pb, d.BP, ps);
     carve_face(fb, d.BF, (size_t)s->F, (size_t)s->T, tet, fs);
     carve_image(ib, (size_t)s->B, (size_t)d.ntiles, d.npix, tet, is);
-    SizeRead* sr = size_read();
-    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
-    int* host_R = reinterpret_cast<int*>(sr->slot);
+    const bool async = (s->flags & DMR_FLAG_ASYNC) != 0 || stream_is_capturing(st);
+    int dev = 0;
+    DMR_HIP(hipGetDevice(&dev));
+    uint32_t* overflow = overflow_word(dev, !async);
 
-    // write_host: the scan also stores R in the pinned slot.  Not on the redo pass: R is known by then, and a late
-    // store could land in the slot after this call has returned and a later call (another stream) reuses it.
-    auto front = [&](bool write_host) -> int {
+    // host_R: pinned slot the scan also stores R into (null: not needed).  Not on a redo pass: R is known by then, and
+    // a late store could land in the slot after this call has returned and a later call (another stream) reuses it.
+    auto front = [&](int* host_R, uint64_t capacity, uint32_t* ovf) -> int {
         // (tile_count | tile_hits are contiguous: zeroed by k_project_verts, a slice per block)
         dmr::launch_project_verts(*s, ps.vproj, is.mats, is.tile_count, (size_t)(is.scan_tmp + dmr::SCAN_TMP_BUCKETS - is.tile_count), st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
-        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, write_host ? host_R : nullptr, is.tile_order, is.scan_tmp, st);
+        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, is.tile_order,
+                               is.scan_tmp, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffu), ovf, st);
         return 0;
     };
     auto rest = [&](uint64_t capacity) -> int {
@@ -219,7 +247,19 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (it != g_size_cache.end() && it->second.rendered_per_face > 0.0)
             guess = std::min<uint64_t>(padded((uint64_t)(it->second.rendered_per_face * (double)d.BF)), 0x7fffffffu);
     }
-    if (front(true)) return 1;
+    if (async) {  // no host wait at all: capacity from the estimate, overflow checked on the device
+        if (!guess || !overflow)
+            return fail("asynchronous / captured call without a size estimate: run one default (waiting) call with the same "
+                        "view configuration first");
+        if (front(nullptr, guess, overflow) || rest(guess)) return 1;
+        *num_rendered = (int)guess;  // the capacity: an upper bound the backward accepts in R's place
+        DMR_HIP(hipGetLastError());
+        return 0;
+    }
+    SizeRead* sr = size_read();
+    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
+    int* host_R = reinterpret_cast<int*>(sr->slot);
+    if (front(host_R, ~0ull, nullptr)) return 1;
     DMR_HIP(hipEventRecord(sr->ev, st));
     if (guess && rest(guess)) return 1;
     DMR_HIP(hipEventSynchronize(sr->ev));  // the forward's one host wait (rasterizer_impl.cu:287-292): 4 bytes
@@ -230,7 +270,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (rest((uint64_t)R)) return 1;
     } else if ((uint64_t)R > guess) {  // the guess was too small: redo binning + render with the exact size
         DMR_HIP(hipStreamSynchronize(st));
-        if (front(false) || rest((uint64_t)R)) return 1;
+        if (front(nullptr, ~0ull, nullptr) || rest((uint64_t)R)) return 1;
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
@@ -308,6 +348,17 @@ const char* dmr_stage_name(int stage) {
 }
 
 const char* dmr_last_error(void) { return g_err.c_str(); }
+
+int dmr_overflowed(int device, int reset) {
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 0;
+    uint32_t* w = overflow_word(dev, false);
+    if (!w) return 0;
+    volatile uint32_t* v = w;
+    const int r = *v != 0u;
+    if (reset) *v = 0u;
+    return r;
+}
 int dmr_abi_version(void) { return DMR_ABI_VERSION; }
 const char* dmr_build_arch(void) { return "gfx950"; }
 
@@ -357,9 +408,10 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
 
     // The forward counted the blended (pixel, face) pairs per tile and in total; the total sizes the record
     // buffer (the backward's one 8-byte host read; speculative sizing as in the forward).
-    SizeRead* sr = size_read();
-    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
-    unsigned long long* host_total = reinterpret_cast<unsigned long long*>(sr->slot);
+    const bool async = (s->flags & DMR_FLAG_ASYNC) != 0 || stream_is_capturing(st);
+    int dev = 0;
+    DMR_HIP(hipGetDevice(&dev));
+    uint32_t* overflow = overflow_word(dev, !async);
     const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
     const size_t pbytes = up(sizeof(float4) * 2 * d.npix);
     auto rest = [&](uint64_t capacity) -> int {
@@ -390,10 +442,22 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
         auto it = g_size_cache.find(key);
-        if (it != g_size_cache.end() && it->second.hits_per_rendered > 0.0)
-            guess = std::min<uint64_t>(padded((uint64_t)(it->second.hits_per_rendered * (double)num_rendered)), 0xfffffffeull);
+        if (it != g_size_cache.end() && it->second.hits_per_face > 0.0)
+            guess = std::min<uint64_t>(padded((uint64_t)(it->second.hits_per_face * (double)d.BF)), 0xfffffffeull);
     }
-    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, host_total, is.scan_tmp, st);
+    if (async) {  // no host wait: see run_forward
+        if (!guess || !overflow)
+            return fail("asynchronous / captured call without a size estimate: run one default (waiting) backward with the "
+                        "same view configuration first");
+        dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, nullptr, is.scan_tmp, (uint32_t)guess, overflow, st);
+        if (rest(guess)) return 1;
+        DMR_HIP(hipGetLastError());
+        return 0;
+    }
+    SizeRead* sr = size_read();
+    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
+    unsigned long long* host_total = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sr->slot) + 8);
+    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, host_total, is.scan_tmp, 0xffffffffu, nullptr, st);
     DMR_HIP(hipEventRecord(sr->ev, st));
     if (guess && rest(guess)) return 1;
     DMR_HIP(hipEventSynchronize(sr->ev));
@@ -407,7 +471,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
-        g_size_cache[key].hits_per_rendered = (double)std::max<uint64_t>(nhits, 1) / (double)num_rendered;
+        g_size_cache[key].hits_per_face = (double)std::max<uint64_t>(nhits, 1) / (double)std::max<size_t>(d.BF, 1);
     }
     DMR_HIP(hipGetLastError());
     return 0;
@@ -551,6 +615,7 @@ int64_t dmr_export(const dmr_scene* s, int is_tet, int num_rendered, const char*
     if (n == "final_T") return plain(is.final_T, d.npix * 4);
     if (n == "final_prev_T") return plain(is.final_prev_T, d.npix * 4);
     if (n == "n_contrib") return plain(is.n_contrib, d.npix * 4);
+    if (n == "tile_hits") return is_tet ? -1 : plain(is.tile_hits, (size_t)d.ntiles * 4);
     if (is_tet) {
         if (n == "first_face") return plain(is.first_face, d.npix * 4);
         if (n == "first_tet") return plain(is.first_tet, d.npix * 4);

@@ -34,8 +34,11 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
 // scan_tmp: scan_tmp_words(ntiles) u32 of scratch whose first SCAN_TMP_BUCKETS words are zero on entry
 constexpr int SCAN_TMP_BUCKETS = 128;
 size_t scan_tmp_words(int ntiles);
+// host_num_rendered (pinned, may be null): receives R.  overflow (pinned, may be null): set to 1 when R > capacity
+// (asynchronous calls, which never read R on the host)
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
-                       int* num_rendered, int* host_num_rendered, uint32_t* tile_order, uint32_t* scan_tmp, hipStream_t st);
+                       int* num_rendered, int* host_num_rendered, uint32_t* tile_order, uint32_t* scan_tmp,
+                       uint32_t capacity, uint32_t* overflow, hipStream_t st);
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
                           const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
                           hipStream_t st);
@@ -60,7 +63,8 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
                         float* out_color, float* out_depth, hipStream_t st);
 // host_*: pinned host memory the kernel also writes its total to (no separate device->host copy)
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
-                      unsigned long long* host_hit_total, uint32_t* scan_tmp, hipStream_t st);
+                      unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity, uint32_t* overflow,
+                      hipStream_t st);
 // also zeroes work[0, work_floats) (the packed accumulators)
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,

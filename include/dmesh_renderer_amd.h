@@ -15,8 +15,9 @@
  * tensors are dense row-major fp32 / int32 exactly as render.cu hands them down
  * (`.contiguous().data<T>()`), matrices are [B,16] column-major m[4*col+row]
  * (auxiliary.h:71-90) unless dmr_scene.mats_transposed says otherwise.  `stream` is a hipStream_t (NULL = default stream).  All work
- * is enqueued on that stream; the only host synchronisation is the 4-byte read of
- * num_rendered in the forward calls (reference: rasterizer_impl.cu:287-292).
+ * is enqueued on that stream; the only host synchronisation is the wait for the 4-byte num_rendered in the forward
+ * calls and for the 8-byte record count in the tri backward (reference: rasterizer_impl.cu:287-292), and not even that
+ * with DMR_FLAG_ASYNC or under stream capture ("Sizes only the device knows" below).
  *
  * Return value: 0 on success, non-zero on error; dmr_last_error() then returns a
  * message for the calling thread (the glue raises RuntimeError with it, as the
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DMR_ABI_VERSION 2
+#define DMR_ABI_VERSION 3
 
 /* Scratch buffers.  The first four are the reference's pointBuffer / faceBuffer /
  * binningBuffer / imageBuffer (rasterizer.h:14-17): opaque byte buffers that the
@@ -76,7 +77,26 @@ typedef struct dmr_scene {
      * render.cu:117-120.  The forward stores the matrices in contract layout in the image buffer; the
      * backward reads them from there (its matrix arguments are not dereferenced). */
     int32_t mats_transposed;
+    /* DMR_FLAG_* bits.  DMR_FLAG_ASYNC: the call never waits for the device (see "Sizes only the device knows"). */
+    int32_t flags;
 } dmr_scene;
+
+/* Sizes only the device knows.  R (the binning buffer's entries, `num_rendered`) and the number of blended (pixel,
+ * face) pairs (the tri backward's record buffer) are results of kernels.  The reference stalls on a device->host copy of
+ * R before it can go on (rasterizer_impl.cu:287-299).  Here a call sizes both buffers from the previous call with the
+ * same view configuration (+25 %), enqueues everything, and
+ *   - by default waits on an event behind the scan kernel (which writes the size to pinned memory) -- the GPU keeps
+ *     running -- returns the exact R and redoes the affected stages if the estimate was too small;
+ *   - with DMR_FLAG_ASYNC, or when `stream` is being captured into a HIP graph (hipStreamIsCapturing), does not wait at
+ *     all: *num_rendered receives the CAPACITY it used (an upper bound that the backward accepts in R's place), every
+ *     kernel clamps to it, and a scene that outgrew it sets a sticky per-device flag that dmr_overflowed() reports --
+ *     the results of such a call are incomplete (tiles beyond the capacity render as empty) and the caller repeats the
+ *     step with a default (waiting) call, which refreshes the estimate.  Needs one earlier default call with the same
+ *     view configuration (the warm-up before a capture), else it fails. */
+#define DMR_FLAG_ASYNC 1
+/* 1 if an asynchronous / captured call on `device` (-1: the current one) overflowed its capacity since the flag was
+ * last reset; call it after the stream (or the graph launch) has completed.  reset != 0 clears the flag. */
+int dmr_overflowed(int device, int reset);
 
 /* out_color [B,3,H,W], out_depth [B,1,H,W]: every pixel of the rendered tile rows is written; the caller
  * zero-initialises them (render.cu:88-89) when a band leaves rows untouched or when P == 0 / F == 0
@@ -116,7 +136,7 @@ int dmr_invert_mats(const float* in, int count, int transposed, float* out, void
 /* Parity/debug export of forward intermediates held in the scratch buffers.
  * name: "image" (f32 [B*P,2]) "ndc_z" (f32 [B*P]) "key_depth" (f32 [B*F]) "max_depth" (tet, f32 [B*F])
  * "tiles_touched" (u32 [B*F]) "ranges" (u32 [B*Nt,2]) "face_list" (u32 [R]) "final_T" "final_prev_T"
- * (f32 [B*W*H]) "n_contrib" (u32 [B*W*H]) "first_face" "first_tet" "last_face" "last_tet" (i32, tet)
+ * (f32 [B*W*H]) "n_contrib" (u32 [B*W*H]) "tile_hits" (tri, u32 [B*Nt]: blended (pixel, face) pairs per tile) "first_face" "first_tet" "last_face" "last_tet" (i32, tet)
  * "is_active" (u8, tet).  dst is a DEVICE pointer with room for `cap` bytes.  Returns the byte size
  * of the item (copying min(size, cap) when dst != NULL), or -1. */
 int64_t dmr_export(const dmr_scene* scene, int is_tet, int num_rendered, const char* name,

@@ -1,8 +1,8 @@
-"""ctypes binding of the C ABI in include/dmesh_renderer_amd.h.
-
-There is no fallback: if libdmesh_renderer_hip.so is missing or does not export the ABI,
-importing the renderer fails loudly.  torch is imported first so that the library binds to
-the HIP runtime already loaded by PyTorch-ROCm (one runtime per process).
+"""ctypes view of the C ABI in include/dmesh_renderer_amd.h -- TEST INFRASTRUCTURE (tests/test_capi_cpu.py): the
+product's binding is the compiled module dmesh_renderer_amd._C (csrc/dmr_torch.cpp); this table restates the header
+in a second, independent form so that the library's exports, the struct layout and the version can be checked without
+a GPU, and shows what a non-PyTorch host would bind.  torch is imported first so that the library
+binds to the HIP runtime already loaded by PyTorch-ROCm (one runtime per process).
 """
 from __future__ import annotations
 
@@ -11,10 +11,9 @@ import os
 
 import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-# DMR_LIBRARY=<path>: load another build of the same C ABI (the ablation build of build.py --ablation, a tuning build)
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dmesh_renderer_amd")
 LIB_PATH = os.environ.get("DMR_LIBRARY") or os.path.join(HERE, "libdmesh_renderer_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 BUF_POINT, BUF_FACE, BUF_BINNING, BUF_IMAGE, BUF_WORK = range(5)
 NUM_STAGES = 12
@@ -32,7 +31,7 @@ class Scene(C.Structure):
         ("verts_depth", C.c_void_p), ("faces_intense", C.c_void_p),
         ("tets", C.c_void_p), ("face_tets", C.c_void_p), ("tet_faces", C.c_void_p),
         ("ray_random_seed", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
-        ("mats_transposed", C.c_int32),
+        ("mats_transposed", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -52,6 +51,7 @@ EXPORTS = {
     "dmr_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dmr_stage_name": (C.c_char_p, [C.c_int]),
     "dmr_last_error": (C.c_char_p, []),
+    "dmr_overflowed": (C.c_int, [C.c_int, C.c_int]),
     "dmr_abi_version": (C.c_int, []),
     "dmr_build_arch": (C.c_char_p, []),
 }

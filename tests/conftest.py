@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native pieces (HIP library + compiled binding) are prerequisites of the renderer; this is a no-op when they
+    # are up to date (__graft_entry__.build() made them; they travel to the GPU box prebuilt)
+    from dmesh_renderer_amd import build
+    build.build_all()
 
 
 @pytest.fixture(scope="session")

@@ -25,7 +25,8 @@ def test_header_declares_the_four_entry_points():
 
 
 def test_library_exports_every_declared_symbol():
-    from dmesh_renderer_amd import _lib, build
+    import capi_ctypes as _lib
+    from dmesh_renderer_amd import build
     build.build()
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in _declared_functions():
@@ -35,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_binding_loads_and_reports_arch():
-    from dmesh_renderer_amd import _lib
+    import capi_ctypes as _lib
     lib = _lib.load()
     assert lib.dmr_build_arch() == b"gfx950"
     assert lib.dmr_abi_version() == _lib.ABI_VERSION
@@ -43,10 +44,27 @@ def test_binding_loads_and_reports_arch():
 
 
 def test_scene_struct_layout_matches_header():
-    """dmr_scene: 6 int32, 14 pointers, 3 int32 (natural alignment)."""
-    from dmesh_renderer_amd import _lib
-    assert ctypes.sizeof(_lib.Scene) == 6 * 4 + 14 * 8 + 3 * 4 + 4  # + tail padding to 8
+    """dmr_scene: 6 int32, 14 pointers, 5 int32 (natural alignment)."""
+    import capi_ctypes as _lib
+    assert ctypes.sizeof(_lib.Scene) == 6 * 4 + 14 * 8 + 5 * 4 + 4  # + tail padding to 8
     assert _lib.Scene.background.offset == 24 and _lib.Scene.ray_random_seed.offset == 24 + 14 * 8
+
+
+def test_compiled_binding_is_the_only_one():
+    """`_C` is a compiled extension module over the C ABI (no ctypes / pure-Python binding left in the product) and
+    it is bound to the in-tree HIP library."""
+    import dmesh_renderer_amd as dmr
+    from dmesh_renderer_amd import _C
+    assert _C.__file__.endswith(".so") and os.path.dirname(_C.__file__) == os.path.dirname(dmr.__file__)
+    assert _C.library_path() == os.path.join(os.path.dirname(dmr.__file__), "libdmesh_renderer_hip.so")
+    assert _C.ABI_VERSION == 3 and _C.build_arch() == "gfx950" and _C.NUM_STAGES == 12
+    assert _C.stage_name(_C.STAGE_TRI_BACKWARD_HITS) == "k_tri_backward_hits"
+    for n in ("render_tris", "render_tris_backward", "render_tets", "render_tets_backward"):  # ext.cpp:6-11
+        assert callable(getattr(_C, n))
+    pkg = os.path.dirname(dmr.__file__)
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert "ctypes" not in open(os.path.join(pkg, f)).read(), f
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,174 @@
+"""no device->host stall on the steady-state path, and a step that can be captured into a HIP graph.
+
+The reference stalls on a 4-byte copy of num_rendered in every forward (rasterizer_impl.cu:287-299) and allocates through
+four torch resize_ calls (render.cu:18-24,91-100).  Here:
+  * asynchronous calls (`_C.set_async(True)`, C ABI DMR_FLAG_ASYNC) size their buffers from the previous call and never
+    wait; a scene that outgrew the estimate raises the sticky overflow flag instead of producing a silent wrong answer;
+  * under stream capture the library takes that path by itself, so Module forward + autograd backward are captured as ONE
+    graph and replayed with new input values -- checked against the oracle on every replay.
+"""
+import numpy as np
+import pytest
+import torch as th
+
+import dmesh_renderer_amd as dmr
+from dmesh_renderer_amd import scenes
+from util import c_args, rel_err, upstream_grads
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL = 1e-5, 1e-4
+TRI_NAMES = ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")
+
+
+def _oracle_tri(oracle, d, H, W, gc, gd):
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    oc, od, ost = oracle.tri_forward(sc)
+    return oc, od, oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+
+
+def test_tri_step_replays_as_one_graph(hip_device, oracle):
+    """Capture TriRenderer forward + backward (through autograd) once, replay it three times with new colours,
+    opacities and slightly moved vertices copied into the captured tensors; every replay must match the oracle."""
+    dev = hip_device
+    cfg = scenes.CONFIGS["C1"]
+    B, H, W = cfg.B, cfg.H, cfg.W
+    d = scenes.make("C1")
+    gc, gd = upstream_grads(B, H, W)
+    static = {k: v.to(dev) for k, v in d.items()}
+    leaves = {k: static[k].clone().requires_grad_(True) for k in TRI_NAMES}
+    faces = static["faces"].to(th.int32)
+    gcd, gdd = gc.to(dev), gd.to(dev)
+    r = dmr.TriRenderer(dmr.TriRenderSettings(H, W, static["bg"]))
+
+    def step():
+        color, depth = r(leaves["verts"], faces, leaves["verts_color"], leaves["faces_opacity"], static["mv_mats"],
+                         static["proj_mats"], leaves["verts_depth"], leaves["faces_intense"])
+        th.autograd.backward([color, depth], [gcd, gdd])
+        return color, depth
+
+    # warm-up on a side stream: default (waiting) calls, which also leave the size estimates the captured calls need
+    s = th.cuda.Stream()
+    s.wait_stream(th.cuda.current_stream())
+    with th.cuda.stream(s):
+        for _ in range(2):
+            step()
+    th.cuda.current_stream().wait_stream(s)
+    for v in leaves.values():
+        v.grad = None
+    dmr._C.overflowed()  # clear
+    g = th.cuda.CUDAGraph()
+    with th.cuda.graph(g):
+        color, depth = step()
+    gen = th.Generator().manual_seed(11)
+    for it in range(3):
+        d2 = dict(d)
+        d2["verts_color"] = th.rand(d["verts_color"].shape, generator=gen)
+        d2["faces_opacity"] = th.rand(d["faces_opacity"].shape, generator=gen) * 0.5 + 0.05
+        d2["verts"] = d["verts"] + 0.002 * th.randn(d["verts"].shape, generator=gen) * th.tensor([1.0, 1.0, 0.0])
+        with th.no_grad():
+            for k in ("verts", "verts_color", "faces_opacity"):
+                leaves[k].copy_(d2[k].to(dev))
+        g.replay()
+        th.cuda.synchronize()
+        assert not dmr._C.overflowed(), "the replayed scene outgrew the captured capacity"
+        oc, od, og = _oracle_tri(oracle, d2, H, W, gc, gd)
+        assert np.abs(color.detach().cpu().numpy() - oc).max() <= FWD_TOL and np.abs(depth.detach().cpu().numpy() - od).max() <= FWD_TOL, it
+        for k in TRI_NAMES:
+            assert rel_err(leaves[k].grad.cpu().numpy(), og[k]) <= GRAD_TOL, (it, k)
+
+
+def test_tet_step_replays_as_one_graph(hip_device, oracle):
+    dev = hip_device
+    B, H, W = 1, 160, 160
+    d = scenes.kuhn_tets(5, B, H, W, seed=1)
+    gc, gd = upstream_grads(B, H, W)
+    t = {k: v.to(dev) for k, v in d.items()}
+    vc = t["verts_color"].clone().requires_grad_(True)
+    fo = t["faces_opacity"].clone().requires_grad_(True)
+    topo = [t[k].to(th.int32) for k in ("faces", "tets", "face_tets", "tet_faces")]
+    gcd, gdd = gc.to(dev), gd.to(dev)
+    r = dmr.TetRenderer(dmr.TetRenderSettings(H, W, t["bg"], 0))
+
+    def step():
+        color, depth, active = r(t["verts"], topo[0], vc, fo, t["mv_mats"], t["proj_mats"], t["verts_depth"], t["faces_intense"],
+                                 topo[1], topo[2], topo[3])
+        th.autograd.backward([color, depth], [gcd, gdd])
+        return color, depth, active
+
+    s = th.cuda.Stream()
+    s.wait_stream(th.cuda.current_stream())
+    with th.cuda.stream(s):
+        for _ in range(2):
+            step()
+    th.cuda.current_stream().wait_stream(s)
+    vc.grad = None; fo.grad = None
+    dmr._C.overflowed()
+    g = th.cuda.CUDAGraph()
+    with th.cuda.graph(g):
+        color, depth, active = step()
+    gen = th.Generator().manual_seed(5)
+    for it in range(3):
+        d2 = dict(d)
+        d2["verts_color"] = th.rand(d["verts_color"].shape, generator=gen)
+        d2["faces_opacity"] = th.rand(d["faces_opacity"].shape, generator=gen) * 0.3 + 0.02
+        with th.no_grad():
+            vc.copy_(d2["verts_color"].to(dev)); fo.copy_(d2["faces_opacity"].to(dev))
+        g.replay()
+        th.cuda.synchronize()
+        assert not dmr._C.overflowed()
+        sc = oracle.scene_from_module_inputs(d2, H, W)
+        oc, od, oa, ost = oracle.tet_forward(sc)
+        og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+        assert np.array_equal(active.cpu().numpy(), oa > 0.5)
+        assert np.abs(color.detach().cpu().numpy() - oc).max() <= FWD_TOL and np.abs(depth.detach().cpu().numpy() - od).max() <= FWD_TOL
+        assert rel_err(vc.grad.cpu().numpy(), og["verts_color"]) <= GRAD_TOL and rel_err(fo.grad.cpu().numpy(), og["faces_opacity"]) <= GRAD_TOL
+
+
+def test_async_calls_never_wait_and_flag_overflow(hip_device, oracle):
+    from dmesh_renderer_amd import _C
+    dev = hip_device
+    B, H, W = 2, 232, 312  # a view configuration no other test uses: the size cache is keyed by it
+    d = scenes.layered_sheets(3, 12, B, H, W, seed=2)
+    gc, gd = upstream_grads(B, H, W)
+    args = c_args(d, dev)
+    gcd, gdd = gc.to(dev), gd.to(dev)
+    oc, od, og = _oracle_tri(oracle, d, H, W, gc, gd)
+    _C.overflowed()
+    try:
+        _C.set_async(True)
+        assert _C.is_async()
+        with pytest.raises(RuntimeError, match="without a size estimate"):  # nothing to size the buffers from yet
+            _C.render_tris(*args, H, W)
+        _C.set_async(False)
+        ref = _C.render_tris(*args, H, W)  # default call: exact R, leaves the estimate
+        gref = _C.render_tris_backward(*args, gcd, gdd, ref[0], *ref[3:7])
+        _C.set_async(True)
+        out = _C.render_tris(*args, H, W)
+        g = _C.render_tris_backward(*args, gcd, gdd, out[0], *out[3:7])
+        th.cuda.synchronize()
+        assert out[0] >= ref[0]  # the capacity stands in for R
+        assert not _C.overflowed()
+        assert th.equal(out[1], ref[1]) and th.equal(out[2], ref[2])
+        assert np.abs(out[1].cpu().numpy() - oc).max() <= FWD_TOL
+        for a, k in zip(g, TRI_NAMES):
+            assert rel_err(a.cpu().numpy(), og[k]) <= GRAD_TOL, k
+        # a scene that grows far beyond the estimate: the asynchronous call cannot redo, it must say so
+        # (the estimate is list entries per face: 100 sheets of 8 triangles that each cover dozens of tiles, after a mesh of
+        # small ones)
+        big = scenes.layered_sheets(100, 3, B, H, W, seed=3, opacity=(0.01, 0.05))
+        bargs = c_args(big, dev)
+        _C.render_tris(*bargs, H, W)
+        th.cuda.synchronize()
+        assert _C.overflowed(), "overflow of an asynchronous call must be reported"
+        assert not _C.overflowed(), "the flag is cleared by the read"
+        # ... and the default call repairs it: exact sizes, oracle parity
+        _C.set_async(False)
+        o2 = _C.render_tris(*bargs, H, W)
+        g2 = _C.render_tris_backward(*bargs, gcd, gdd, o2[0], *o2[3:7])
+        boc, bod, bog = _oracle_tri(oracle, big, H, W, gc, gd)
+        assert np.abs(o2[1].cpu().numpy() - boc).max() <= FWD_TOL
+        for a, k in zip(g2, TRI_NAMES):
+            assert rel_err(a.cpu().numpy(), bog[k]) <= GRAD_TOL, k
+    finally:
+        _C.set_async(False)
+        _C.overflowed()
