@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing table to stderr")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous only (gloo, no GPU): prints n_gpus")
+    ap.add_argument("--emulate-rank", default=None, metavar="R/N",
+                    help="one process, no collective: time rank R's tile-row band of an N-rank run (for rocprofv3 traces of the per-rank work)")
     return ap.parse_args()
 
 
@@ -182,8 +184,12 @@ def main():
     else:    # blended (pixel, face) pairs: what the backward's record stream holds
         stats["blended_pairs"] = int(_C.export("tile_hits", args, False, out[0], bufs, H, W, th.int32).long().sum().item())
     rows = (0, 0)
-    if world > 1:
-        rows = balanced_bands(row_work_from_ranges(ranges, B, gy, gx), world)[rank]
+    emu = None
+    if a.emulate_rank:
+        emu = tuple(int(x) for x in a.emulate_rank.split("/"))
+        assert world == 1 and 0 <= emu[0] < emu[1]
+    if world > 1 or emu:
+        rows = balanced_bands(row_work_from_ranges(ranges, B, gy, gx), emu[1] if emu else world)[emu[0] if emu else rank]
         if rows[1] <= rows[0]:
             rows = (gy, gy)  # an empty band ((0, 0) would mean "all rows")
     del out, bufs
@@ -193,7 +199,7 @@ def main():
     def step():
         o = forward(rows, fill=False)  # a rank only owns the rows of its band
         kw = {}
-        if world > 1:  # the gradients land back to back in `flat` (views are returned): ONE collective, no concatenation
+        if world > 1 or emu:  # the gradients land back to back in `flat` (views are returned): ONE collective, no concatenation
             kw = dict(rows=rows, flat_out=flat)
         if tet:
             g = _C.render_tets_backward(*args, gc, gd, *o[-4:], **kw)
@@ -254,7 +260,7 @@ def main():
     #   k_tet_forward / k_tet_backward     : 508 / 548 B per marched (pixel, face) pair S: the reference's gathers per
     #       march step, 16+12+36+36+4+4+3*(12+36)+4*(16+48), + 40 B of atomics in the backward
     # (the hit-record stream between the two tri backward kernels is this design's own traffic, not algorithmic)
-    if world > 1:  # this rank's band
+    if world > 1 or emu:  # this rank's band
         br = _C.export("ranges", args, tet, 0 if tet else o[0], o[-4:], H, W, th.int32).cpu().numpy().reshape(-1, 2).astype(np.int64)
         R = int((br[:, 1] - br[:, 0]).sum())
         npix_band = B * W * max(0, min(H, rows[1] * 16) - rows[0] * 16)
@@ -280,7 +286,7 @@ def main():
 
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, scripts/prof_traffic.sh)
     traffic, valu = None, None
-    if world == 1 and not a.opacity:
+    if world == 1 and not a.opacity and not emu:
         tj, _ = committed("traffic")
         traffic = (tj or {}).get("hbm_bytes_per_launch")
         # secondary figure: VALU issue.  SQ_INSTS_VALU wave-instructions per launch (committed PMC pass) x 2.25
@@ -312,7 +318,7 @@ def main():
     # second record: the same scene with opacities U(0.5, 0.95) -- pixels terminate after a few faces, which
     # exercises the early-out of the compositing loops
     early = None
-    if world == 1 and not tet and not a.opacity and not a.no_early_out and rank == 0:
+    if world == 1 and not tet and not a.opacity and not a.no_early_out and not emu and rank == 0:
         d2 = scenes.make(a.config, opacity=(0.5, 0.95))
         args2 = c_args(d2, dev)
         def step2():
@@ -334,7 +340,7 @@ def main():
 
     cpu_baseline = None
     parity = {}
-    if world == 1 and not a.no_cpu_baseline and rank == 0:
+    if world == 1 and not a.no_cpu_baseline and not emu and rank == 0:
         from oracle import oracle as O  # checker / reported baseline only
         O.build()
         sc = O.scene_from_module_inputs(d, H, W)
@@ -374,7 +380,8 @@ def main():
             "config": dict({"workload": f"{a.config}: {cfg.name}, {'Kuhn lattice' if tet else 'layered sheets'} seed 0, B={B}"
                                         + (f", opacity U({a.opacity})" if a.opacity else ""),
                             "renderer": cfg.kind, "triangles": F, "verts": P, "image": [H, W], "num_rendered": int(R_full),
-                            "parallelism": "single GPU" if world == 1 else f"tile-row bands x{world} + 1 RCCL all-reduce"}, **stats),
+                            "parallelism": (f"EMULATED rank {emu[0]} of {emu[1]}: its tile-row band {rows}, no collective" if emu else
+                                            "single GPU" if world == 1 else f"tile-row bands x{world} + 1 RCCL all-reduce")}, **stats),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stages, "early_out": early,
         }
         if tet:

@@ -50,7 +50,7 @@ struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* ti
 struct ImageState {
     uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_cursor; int* num_rendered;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits; uint32_t* scan_tmp; uint32_t* hit_offset; unsigned long long* hit_total; uint32_t* tile_order;
+    uint32_t* tile_hits; uint32_t* scan_tmp; uint32_t* hit_offset; uint32_t* tile_used; unsigned long long* hit_total; uint32_t* tile_order;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
     int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
@@ -78,7 +78,7 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
     // counters, zeroed by k_project_verts at the start of a forward: [tile_count | tile_hits | scan_tmp's buckets]
     s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles);
     s.scan_tmp = c.take<uint32_t>(dmr::scan_tmp_words((int)ntiles));
-    s.hit_offset = c.take<uint32_t>(ntiles + 1); s.hit_total = c.take<unsigned long long>(1);
+    s.hit_offset = c.take<uint32_t>(ntiles + 1); s.tile_used = c.take<uint32_t>(ntiles); s.hit_total = c.take<unsigned long long>(1);
     s.tile_offset = c.take<uint32_t>(ntiles + 1);
     s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(1);
     s.tile_order = c.take<uint32_t>(ntiles);
@@ -372,7 +372,7 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_order};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order};
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, bs.capacity, img, out_color,
                                 out_depth, st);
@@ -413,7 +413,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     DMR_HIP(hipGetDevice(&dev));
     uint32_t* overflow = overflow_word(dev, !async);
     const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
-    const size_t pbytes = up(sizeof(float4) * 2 * d.npix);
+    const size_t pbytes = up(sizeof(float4) * 2 * (size_t)d.ntiles * dmr::TILE_PIX);  // per tile: its 256 pixels' (ray, upstream gradient) records
     auto rest = [&](uint64_t capacity) -> int {
         const size_t hbytes = up(sizeof(dmr::HitRecord) * (size_t)capacity);
         char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes + pbytes + hbytes));
@@ -422,7 +422,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         float* frow = reinterpret_cast<float*>(work + vbytes);
         float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
         dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_order};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order};
         const dmr_scene sc = canonical(s, is.mats);
         // (Splitting the tiles into bands whose hit-parallel kernel runs on a second stream while the next band's
         // per-pixel kernel computes -- atomic unit and SIMDs busy at the same time -- was measured and lost: 0.56 ms
@@ -433,7 +433,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         dmr::launch_tri_backward_pix(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img,
                                      dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity,
                                      reinterpret_cast<float*>(work), (vbytes + fbytes) / sizeof(float), st);
-        dmr::launch_tri_backward_hits(sc, ps.vproj, bs.face_list, pixrec, hits, is.hit_total, (uint32_t)capacity, vrow, frow, st);
+        dmr::launch_tri_backward_hits(sc, d.gx, d.gy, ps.vproj, bs.face_list, img, pixrec, hits, (uint32_t)capacity, vrow, frow, st);
         dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
         return 0;
     };
@@ -449,7 +449,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         if (!guess || !overflow)
             return fail("asynchronous / captured call without a size estimate: run one default (waiting) backward with the "
                         "same view configuration first");
-        dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, nullptr, is.scan_tmp, (uint32_t)guess, overflow, st);
+        dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, nullptr, is.scan_tmp, (uint32_t)guess, overflow, st);
         if (rest(guess)) return 1;
         DMR_HIP(hipGetLastError());
         return 0;
@@ -457,7 +457,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     SizeRead* sr = size_read();
     if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
     unsigned long long* host_total = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sr->slot) + 8);
-    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.hit_offset, is.hit_total, host_total, is.scan_tmp, 0xffffffffu, nullptr, st);
+    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, host_total, is.scan_tmp, 0xffffffffu, nullptr, st);
     DMR_HIP(hipEventRecord(sr->ev, st));
     if (guess && rest(guess)) return 1;
     DMR_HIP(hipEventSynchronize(sr->ev));

@@ -440,6 +440,17 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
     }
 }
 
+// Records a tile's region of the backward's record buffer must hold.  The per-pixel kernel writes a face's blended pairs
+// as one run padded to a multiple of HIT_GROUP records (the hit-parallel kernel takes HIT_GROUP records of ONE list entry
+// per lane), so a tile with h blended pairs (counted by the forward) in a list of `len` entries needs at most
+// h + (HIT_GROUP - 1) * min(len, h) records; rounded up to whole blocks of HIT_BLOCK records (the layout inside a region,
+// dmr_kernels.hpp).
+__device__ __forceinline__ uint32_t record_bound(uint32_t h, uint32_t len) {
+    if (h == 0u) return 0u;
+    const uint32_t b = h + (uint32_t)(HIT_GROUP - 1) * min(len, h);
+    return (b + (uint32_t)(HIT_BLOCK - 1)) & ~(uint32_t)(HIT_BLOCK - 1);
+}
+
 // ---- the same for many tiles (B * tiles > SCAN_SINGLE_MAX: several views at 1080p, 4096^2 images): one workgroup
 // per 8192 tiles, three small launches (partial sums + bucket sizes | scan of the partials | offsets + order) instead
 // of one workgroup streaming everything (0.5 ms for C5's 1 M tiles).
@@ -447,9 +458,10 @@ constexpr int SCAN_BLOCK_TILES = 8192;
 constexpr int SCAN_SINGLE_MAX = SCAN_SLAB;   // up to here one workgroup does it all (k_scan_tiles, k_scan_hits)
 
 // pass 1: blk_sum[block] = sum of the block's counts; bucket_count[b] += tiles of the block in order bucket b
+// (ORDER == false: the scan of the backward's record regions; the counts are record_bound(tile_count, list length))
 template <bool ORDER>
 __global__ void __launch_bounds__(1024)
-k_scan_tiles_partial(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ blk_sum,
+k_scan_tiles_partial(int n, const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ len_offset, uint32_t* __restrict__ blk_sum,
                      uint32_t* __restrict__ bucket_count) {
     __shared__ uint32_t wave_sum[17];
     __shared__ uint32_t bucket[ORDER_CELLS];
@@ -459,7 +471,10 @@ k_scan_tiles_partial(int n, const uint32_t* __restrict__ tile_count, uint32_t* _
     __syncthreads();
     uint32_t c[SCAN_BATCH], local = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_BATCH; j++) c[j] = begin + j < end ? tile_count[begin + j] : 0u;
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        c[j] = begin + j < end ? tile_count[begin + j] : 0u;
+        if (!ORDER && begin + j < end) c[j] = record_bound(c[j], len_offset[begin + j + 1] - len_offset[begin + j]);
+    }
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) {
         local += c[j];
@@ -514,7 +529,7 @@ k_scan_tiles_blocks(int nblk, int n, uint32_t* __restrict__ blk_sum, uint32_t* _
 // pass 3: offsets, cursors and the order
 template <bool ORDER>
 __global__ void __launch_bounds__(1024)
-k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ blk_sum,
+k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ len_offset, const uint32_t* __restrict__ blk_sum,
                    uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
                    uint32_t* __restrict__ tile_order) {
     __shared__ uint32_t wave_sum[17];
@@ -526,7 +541,13 @@ k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_
     uint32_t c[SCAN_BATCH], local = 0;
     int n_empty = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_BATCH; j++) c[j] = begin + j < end ? tile_count[begin + j] : 0u;
+    for (int j = 0; j < SCAN_BATCH; j++) {
+        c[j] = begin + j < end ? tile_count[begin + j] : 0u;
+        if (!ORDER && begin + j < end) {  // record regions: the bound, and tile_used (here: tile_cursor) cleared
+            c[j] = record_bound(c[j], len_offset[begin + j + 1] - len_offset[begin + j]);
+            tile_cursor[begin + j] = 0u;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) {
         local += c[j];
@@ -571,18 +592,23 @@ k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_
     }
 }
 
-// exclusive scan of the per-tile hit counts of the forward: every tile's region of the backward's record buffer
-// (u32 offsets; the total is < 2^32 or the backward fails) and the total
+// exclusive scan of those bounds: every tile's region of the backward's record buffer (u32 offsets; the total is < 2^32 or
+// the backward fails) and the total.  Also clears tile_used (records the per-pixel kernel really wrote, per tile).
 __global__ void __launch_bounds__(1024)
-k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, uint32_t* __restrict__ hit_offset,
-            unsigned long long* __restrict__ hit_total, unsigned long long* __restrict__ host_hit_total,
+k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ hit_offset,
+            uint32_t* __restrict__ tile_used, unsigned long long* __restrict__ hit_total, unsigned long long* __restrict__ host_hit_total,
             uint32_t capacity, uint32_t* __restrict__ overflow) {
     __shared__ uint32_t wave_sum[17];
     __shared__ unsigned long long s_total;
     __shared__ __attribute__((aligned(16))) uint32_t slab[SCAN_SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) s_total = 0ull;
-    slab_load(slab, tile_hits, n, tid);  // n <= SCAN_SLAB
+#pragma unroll
+    for (int j = 0; j < SCAN_BATCH; j++) {  // n <= SCAN_SLAB
+        const int i = j * 1024 + tid;
+        slab[i] = i < n ? record_bound(tile_hits[i], tile_offset[i + 1] - tile_offset[i]) : 0u;
+        if (i < n) tile_used[i] = 0u;
+    }
     __syncthreads();
     uint32_t c[SCAN_BATCH], local = 0;
     slab_read(slab, tid, c);
@@ -756,28 +782,28 @@ void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_of
     const int nblk = (ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES;
     uint32_t* bucket = scan_tmp;
     uint32_t* blk_sum = scan_tmp + SCAN_TMP_BUCKETS;
-    k_scan_tiles_partial<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, blk_sum, bucket);
+    k_scan_tiles_partial<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, nullptr, blk_sum, bucket);
     k_scan_tiles_blocks<<<dim3(1), dim3(1024), 0, st>>>(nblk, ntiles, blk_sum, bucket, tile_offset, num_rendered, host_num_rendered,
                                                         nullptr, nullptr, capacity, overflow);
-    k_scan_tiles_final<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, blk_sum, bucket, tile_offset, tile_cursor, tile_order);
+    k_scan_tiles_final<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, nullptr, blk_sum, bucket, tile_offset, tile_cursor, tile_order);
 }
 
 size_t scan_tmp_words(int ntiles) { return SCAN_TMP_BUCKETS + (size_t)(ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES + 1; }
 
-void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
-                      unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity, uint32_t* overflow,
-                      hipStream_t st) {
+void launch_scan_hits(int ntiles, const uint32_t* tile_hits, const uint32_t* tile_offset, uint32_t* hit_offset, uint32_t* tile_used,
+                      unsigned long long* hit_total, unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity,
+                      uint32_t* overflow, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
     if (ntiles <= SCAN_SINGLE_MAX) {
-        k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, hit_offset, hit_total, host_hit_total, capacity, overflow);
+        k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, tile_offset, hit_offset, tile_used, hit_total, host_hit_total, capacity, overflow);
         return;
     }
     const int nblk = (ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES;
     uint32_t* blk_sum = scan_tmp + SCAN_TMP_BUCKETS;  // the forward's partial sums are no longer needed
-    k_scan_tiles_partial<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, blk_sum, nullptr);
+    k_scan_tiles_partial<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, tile_offset, blk_sum, nullptr);
     k_scan_tiles_blocks<<<dim3(1), dim3(1024), 0, st>>>(nblk, ntiles, blk_sum, nullptr, hit_offset, nullptr, nullptr, hit_total,
                                                         host_hit_total, capacity, overflow);
-    k_scan_tiles_final<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, blk_sum, nullptr, hit_offset, nullptr, nullptr);
+    k_scan_tiles_final<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, tile_offset, blk_sum, nullptr, hit_offset, tile_used, nullptr);
 }
 
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,

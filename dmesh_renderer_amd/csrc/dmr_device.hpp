@@ -202,15 +202,26 @@ __device__ __forceinline__ V3 tet_face_outward_normal(const float* __restrict__ 
 // ---------------------------------------------------------------------------
 struct EdgeSetup { int32_t s0[3], bx[3], by[3]; bool ok; int x0, x1, y0, y1; };  // box: tile-local pixels, inclusive
 
-__device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int y0) {
+// The tile-independent half of that set-up: the
+// three vertices snapped to 28.4 fixed point (auxiliary.h:190-195), the zero-area test (:201-202) and the winding swap
+// (:203-212).
+struct alignas(32) FaceCov { int32_t x1, y1, x2, y2, x3, y3; int32_t ok; int32_t pad; };
+
+__device__ __forceinline__ FaceCov snap_face(V2 p1, V2 p2, V2 p3) {
     const float sub = 16.0f;
     uint32_t x1 = (uint32_t)f2i(p1.x * sub), y1 = (uint32_t)f2i(p1.y * sub);
     uint32_t x2 = (uint32_t)f2i(p2.x * sub), y2 = (uint32_t)f2i(p2.y * sub);
     uint32_t x3 = (uint32_t)f2i(p3.x * sub), y3 = (uint32_t)f2i(p3.y * sub);
-    int32_t area = (int32_t)((x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1));
-    EdgeSetup e;
-    e.ok = (area != 0);
+    const int32_t area = (int32_t)((x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1));
     if (area < 0) { uint32_t t = x2; x2 = x3; x3 = t; t = y2; y2 = y3; y3 = t; }
+    return FaceCov{(int32_t)x1, (int32_t)y1, (int32_t)x2, (int32_t)y2, (int32_t)x3, (int32_t)y3, area != 0 ? 1 : 0, 0};
+}
+
+// The tile-dependent half: edge functions at the tile's first pixel (x0, y0), their steps, the pixel box.
+__device__ __forceinline__ EdgeSetup edge_setup(const FaceCov& f, int x0, int y0) {
+    const uint32_t x1 = (uint32_t)f.x1, y1 = (uint32_t)f.y1, x2 = (uint32_t)f.x2, y2 = (uint32_t)f.y2, x3 = (uint32_t)f.x3, y3 = (uint32_t)f.y3;
+    EdgeSetup e;
+    e.ok = f.ok != 0;
     const uint32_t cx[3] = {x1 - x2, x2 - x3, x3 - x1};
     const uint32_t cy[3] = {y1 - y2, y2 - y3, y3 - y1};
     const uint32_t vx[3] = {x1, x2, x3};
@@ -243,5 +254,8 @@ __device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int
     }
     return e;
 }
+__device__ __forceinline__ EdgeSetup edge_setup(V2 p1, V2 p2, V2 p3, int x0, int y0) { return edge_setup(snap_face(p1, p2, p3), x0, y0); }
+
+static_assert(sizeof(FaceCov) == 32, "FaceCov");
 
 }  // namespace dmr

@@ -16,6 +16,17 @@ namespace dmr {
 // requests) instead of 23 scattered dwords.
 constexpr int VROW = 8;
 constexpr int FROW = 2;
+// Records of one list entry (one face in one tile) form a run padded to a multiple of HIT_GROUP; the hit-parallel backward
+// takes one group per lane (k_tri_backward_pix / k_tri_backward_hits, dmr_tri.hip).
+constexpr int HIT_GROUP = 4;
+// Inside a tile's region the records are stored in blocks of HIT_BLOCK = 64 groups, record q of group l of a block at
+// block * HIT_BLOCK + q * 64 + l: the 64 lanes of a wave read record q of their groups as one contiguous kilobyte
+// (16 cache lines; 64 bytes per lane in memory order would be 64 lines per load instruction, and the hit-parallel kernel
+// is bound by exactly that: line accesses in the texture addresser).  Regions are whole blocks.
+constexpr int HIT_BLOCK = 64 * HIT_GROUP;
+__host__ __device__ inline uint32_t hit_slot_address(uint32_t rel) {  // rel: record index in the tile's face-major order
+    return (rel & ~(uint32_t)(HIT_BLOCK - 1)) + (rel & (uint32_t)(HIT_GROUP - 1)) * 64u + ((rel & (uint32_t)(HIT_BLOCK - 1)) / (uint32_t)HIT_GROUP);
+}
 
 // ---- per-stage HIP-event timing (dmr_api.hip); a no-op unless dmr_profile_enable() set the stage's bit
 struct StageScope {
@@ -51,29 +62,32 @@ void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* 
 struct TriImageState {
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
     uint32_t* tile_hits;    // covered (pixel, face) pairs below n_contrib per tile, counted by the forward
-    const uint32_t* hit_offset;     // exclusive scan of tile_hits (k_scan_hits, backward): record regions
+    const uint32_t* hit_offset;     // record regions: exclusive scan of the tiles' record bounds (k_scan_hits, backward)
+    uint32_t* tile_used;            // records k_tri_backward_pix wrote into a tile's region (padded runs; <= the bound)
     const uint32_t* tile_order;  // all B * gx * gy tiles, longest list first (k_scan_tiles)
 };
 // One blended (pixel, face) pair, written face-major per (tile, chunk, pass) by k_tri_backward_pix and
 // consumed one per lane by k_tri_backward_hits.
 // (A 32-byte record carrying face and vertex ids was tried: kernel 2 did not get faster, kernel 1 got 9 % slower.)
-struct alignas(16) HitRecord { uint32_t entry; uint32_t pixel; float T; float dL_dalpha; };
+struct alignas(16) HitRecord { uint32_t id; uint32_t pixel; float T; float dL_dalpha; };  // id: word (slot mod HIT_GROUP) of {face, v0, v1, v2}; pixel: tile-local
 void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                         const uint32_t* tile_offset, const uint32_t* face_list, uint32_t capacity, TriImageState img,
                         float* out_color, float* out_depth, hipStream_t st);
 // host_*: pinned host memory the kernel also writes its total to (no separate device->host copy)
-void launch_scan_hits(int ntiles, const uint32_t* tile_hits, uint32_t* hit_offset, unsigned long long* hit_total,
-                      unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity, uint32_t* overflow,
-                      hipStream_t st);
+// hit_offset: every tile's region of the record buffer, sized by the bound h + (HIT_GROUP - 1) * min(list length, h) of
+// its h blended pairs (tile_hits); tile_used is cleared (the per-pixel kernel fills it)
+void launch_scan_hits(int ntiles, const uint32_t* tile_hits, const uint32_t* tile_offset, uint32_t* hit_offset, uint32_t* tile_used,
+                      unsigned long long* hit_total, unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity,
+                      uint32_t* overflow, hipStream_t st);
 // also zeroes work[0, work_floats) (the packed accumulators)
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
                              uint32_t capacity, float* work, size_t work_floats, hipStream_t st);
-// the record count min(*hit_total, capacity) is read on the device: the launch does not wait for the host to know it
-void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
-                              uint32_t capacity, float* vrow, float* frow, hipStream_t st);
+// one workgroup per tile (longest list first) over the tile's img.tile_used records
+void launch_tri_backward_hits(const dmr_scene& s, int gx, int gy, const float4* vproj, const uint32_t* face_list, TriImageState img,
+                              const float4* pixrec, const HitRecord* hits, uint32_t capacity, float* vrow, float* frow,
+                              hipStream_t st);
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
                        float* dL_dvcolor, float* dL_dfopacity, float* dL_dvdepth, float* dL_dfintense,
                        hipStream_t st);

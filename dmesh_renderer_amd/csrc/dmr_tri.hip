@@ -70,7 +70,7 @@ struct TriParams {
     const float* inv_mv; const float* inv_proj; const float* faces_intense; const float* bg;
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits; const uint32_t* hit_offset; const uint32_t* tile_order;
+    uint32_t* tile_hits; const uint32_t* hit_offset; uint32_t* tile_used; const uint32_t* tile_order;
 };
 
 // Staging a list entry is a chain of dependent gathers: face_list -> faces (+ opacity, intensity) -> 3 x
@@ -200,14 +200,25 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     const int64_t HW = (int64_t)p.H * p.W;
     const int64_t pix_id = (int64_t)p.W * py + px;
 
-    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
-    if (inside) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
-    const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
-
     // A list that does not fit the binning buffer (only while a size guess is being refuted; everything is redone
     // then) was neither completely scattered nor sorted: its entries are not face ids.  Such a tile renders as empty.
     uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
     if (end > p.list_capacity) begin = end = 0u;
+    if (begin == end) {  // an empty tile (most of a frame: 5 244 of C4's 8 160) is background: no rays, no LDS, no barriers
+        if (inside) {
+            const int64_t bpix = (int64_t)b * HW + pix_id;
+            p.final_prev_T[bpix] = 1.0f; p.final_T[bpix] = 1.0f; p.n_contrib[bpix] = 0u;
+            out_color[((int64_t)b * 3 + 0) * HW + pix_id] = 0.f + 1.0f * p.bg[0];
+            out_color[((int64_t)b * 3 + 1) * HW + pix_id] = 0.f + 1.0f * p.bg[1];
+            out_color[((int64_t)b * 3 + 2) * HW + pix_id] = 0.f + 1.0f * p.bg[2];
+            out_depth[bpix] = 0.f + 1.0f * 1.0f;
+        }
+        return;  // uniform
+    }
+
+    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    if (inside && !DMR_DBG(p, 32)) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
+    const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
 
     float T = 1.0f, pT = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last_contributor = 0, n_hits = 0, n_skipped = 0;
@@ -221,7 +232,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     for (uint32_t base = begin; base < end; base += CHUNK) {
         if (__syncthreads_and(done)) break;  // also fences LDS reuse
         const int n = (int)min((uint32_t)CHUNK, end - base);
-        stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
+        if (!DMR_DBG(p, 64)) stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
         ids = load_face_ids(p, b, face_next);  // in flight while this chunk is composited
         face_next = base + 2 * CHUNK + sj < end ? (int)p.face_list[base + 2 * CHUNK + sj] : -1;
         *reinterpret_cast<uint4*>(&s_pm[tid][0]) = make_uint4(0u, 0u, 0u, 0u);
@@ -280,7 +291,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         for (int dlt = 32; dlt > 0; dlt >>= 1) n_hits += __shfl_xor(n_hits, dlt, 64);
         if (lane == 0 && n_hits) atomicAdd(&p.tile_hits[tile], n_hits);
     }
-    if (inside) {
+    if (inside && !DMR_DBG(p, 128)) {
         const int64_t bpix = (int64_t)b * HW + pix_id;
         p.final_prev_T[bpix] = pT;
         p.final_T[bpix] = T;
@@ -408,7 +419,9 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
     __shared__ uint32_t s_fcnt[CHUNK];              // blended pixels per face of the chunk
-    __shared__ uint32_t s_fcur[CHUNK];              // exclusive scan of s_fcnt, then the claim cursor per face
+    __shared__ uint32_t s_fcur[CHUNK];              // exclusive scan of the padded s_fcnt, then the claim cursor per face
+    __shared__ uint32_t s_fpad[CHUNK];              // first pad slot of the face's run | number of pad slots << 28
+    __shared__ int s_ids[CHUNK][HIT_GROUP];         // face id and its three vertex ids: word q rides in record q of every group
     __shared__ uint32_t s_lim[TILE_PIX];            // per pixel: n_contrib relative to the chunk start, clamped to [0, 64]
     __shared__ uint32_t s_pm[TILE_PIX][CHUNK / 32]; // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
     __shared__ uint32_t s_max_last, s_chunk_hits;
@@ -448,10 +461,12 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         dpc1 = dL_dcolor[((int64_t)b * 3 + 1) * HW + pix_id];
         dpc2 = dL_dcolor[((int64_t)b * 3 + 2) * HW + pix_id];
         dpd = dL_ddepth[bpix];
-        // what kernel 2 needs of this pixel: ray direction and upstream gradient, two 16-byte gathers per hit
-        pixrec[2 * bpix] = make_float4(rd.x, rd.y, rd.z, dpd);
-        pixrec[2 * bpix + 1] = make_float4(dpc0, dpc1, dpc2, 0.f);
     }
+    // what kernel 2 needs of a pixel: ray direction and upstream gradient.  Tile-major (the tile's 256 pixels are 8 KB in a
+    // row): kernel 2's workgroup stages them in LDS with coalesced loads instead of two 16-byte gathers per pair.
+    const int pl = ly * TILE + lx;  // tile-local pixel index
+    pixrec[2 * ((int64_t)tile * TILE_PIX + pl)] = make_float4(rd.x, rd.y, rd.z, dpd);
+    pixrec[2 * ((int64_t)tile * TILE_PIX + pl) + 1] = make_float4(dpc0, dpc1, dpc2, 0.f);
     // backward.cu:293-298 (loop invariant there)
     float bg_dot = 0.f;
     bg_dot += p.bg[0] * dpc0; bg_dot += p.bg[1] * dpc1; bg_dot += p.bg[2] * dpc2;
@@ -469,8 +484,8 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     bool first_pass = true;
     float acr0 = 0, acr1 = 0, acr2 = 0, acrd = 0;
     float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0;
-    const uint32_t pixel = (uint32_t)bpix;
-    const int pl = ly * TILE + lx;  // tile-local pixel index
+    const uint32_t pixel = (uint32_t)pl;  // records carry the tile-local pixel
+    const uint32_t region0 = p.hit_offset[tile];
 
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
     // staging pipeline (threads < CHUNK), chunks walked from the back: chunk ci = list positions [lo, hi) with
@@ -489,6 +504,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         const int n = (int)(hi - lo);
         __syncthreads();  // previous chunk is done with the LDS records, counters and masks
         stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
+        if (tid < CHUNK) *reinterpret_cast<int4*>(&s_ids[tid][0]) = make_int4(ids.face, ids.v0, ids.v1, ids.v2);
         ids = load_face_ids(p, b, face_next);  // in flight while this chunk is processed
         face_next = chunk_face(ci + 2);
         if (tid < CHUNK) s_fcnt[tid] = 0u;
@@ -499,10 +515,17 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         if (!DMR_DBG(p, 4)) rasterize_faces_counted<CHUNK>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // ---- A
         __syncthreads();
         if (wave == 0) {  // ---- S: lane l scans counters [l * PER, (l + 1) * PER)
+            // A face's records form ONE run padded to a multiple of HIT_GROUP (the hit-parallel kernel takes HIT_GROUP
+            // records of one list entry per lane, so its segmented scan runs once per group instead of once per record);
+            // the pad slots are filled here with records that contribute nothing.
             constexpr int PER = CHUNK / 64;
-            uint32_t c[PER]; uint32_t sum = 0;
+            uint32_t c[PER], cp[PER]; uint32_t sum = 0;
 #pragma unroll
-            for (int i = 0; i < PER; i++) { c[i] = s_fcnt[lane * PER + i]; sum += c[i]; }
+            for (int i = 0; i < PER; i++) {
+                c[i] = s_fcnt[lane * PER + i];
+                cp[i] = (c[i] + (uint32_t)(HIT_GROUP - 1)) & ~(uint32_t)(HIT_GROUP - 1);
+                sum += cp[i];
+            }
             uint32_t incl = sum;
 #pragma unroll
             for (int dlt = 1; dlt < 64; dlt <<= 1) {
@@ -511,10 +534,23 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
             }
             uint32_t run = incl - sum;
 #pragma unroll
-            for (int i = 0; i < PER; i++) { s_fcur[lane * PER + i] = run; run += c[i]; }
+            for (int i = 0; i < PER; i++) {
+                s_fcur[lane * PER + i] = run;
+                s_fpad[lane * PER + i] = (run + c[i]) | ((cp[i] - c[i]) << 28);  // first pad slot | number of pad slots
+                run += cp[i];
+            }
             if (lane == 63) s_chunk_hits = incl;
         }
         __syncthreads();
+        if (tid < CHUNK) {  // the pad records of face `tid` (<= HIT_GROUP - 1): they contribute nothing
+            const uint32_t fp = s_fpad[tid], slot0 = hit_cursor - region0 + (fp & 0x0fffffffu), npad = fp >> 28;
+            HitRecord pad; pad.pixel = HIT_SKIPPED; pad.T = 0.f; pad.dL_dalpha = 0.f;
+            for (uint32_t q = 0; q < npad; q++) {
+                const uint32_t addr = region0 + hit_slot_address(slot0 + q);
+                pad.id = (uint32_t)s_ids[tid][(slot0 + q) & (uint32_t)(HIT_GROUP - 1)];
+                if (addr < capacity) hits[addr] = pad;
+            }
+        }
         // ---- B
         uint32_t m[WORDS];
 #pragma unroll
@@ -528,9 +564,10 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
 #pragma unroll
             for (int q = 0; q < WORDS; q++) if (q == w) m[q] = mw & ~(1u << bit);
             const int k = 32 * w + bit;
-            const uint32_t slot = hit_cursor + atomicAdd(&s_fcur[k], 1u);
+            const uint32_t rel = hit_cursor - region0 + atomicAdd(&s_fcur[k], 1u);
+            const uint32_t slot = region0 + hit_slot_address(rel);
             HitRecord hr;
-            hr.entry = begin + lo + (uint32_t)k;
+            hr.id = (uint32_t)s_ids[k][rel & (uint32_t)(HIT_GROUP - 1)];
             const ShadeRec& r = s_shade[k];
             const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
             const V3 Tv = {r.T[0], r.T[1], r.T[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
@@ -576,6 +613,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         }
         hit_cursor += s_chunk_hits;  // stable until the next chunk's scan, two barriers away
     }
+    if (tid == 0) p.tile_used[tile] = hit_cursor - region0;  // what the hit-parallel kernel walks (a multiple of HIT_GROUP)
 }
 
 // ---------------------------------------------------------------------------
@@ -609,36 +647,31 @@ __device__ __forceinline__ F3 load3(const float* __restrict__ a, int id) { retur
 constexpr int STAGE_SEGS = 16;   // segment totals handled per round and wave: 16 x (3 vertex rows + 1 face row) = 64 refs
 constexpr int STAGE_ROW = 28;    // 23 sums, v0, v1, v2, face, view
 #ifndef DMR_VTAB
-#define DMR_VTAB 256
+#define DMR_VTAB 512
 #endif
-#ifndef DMR_FTAB
-#define DMR_FTAB 256
-#endif
-#ifndef DMR_HITS_PER_BLOCK
-#define DMR_HITS_PER_BLOCK 1024
+#ifndef DMR_HITS_UNROLL
+#define DMR_HITS_UNROLL 1
 #endif
 constexpr int VTAB = DMR_VTAB;   // vertex-row slots per workgroup (power of two)
-constexpr int FTAB = DMR_FTAB;   // face-row slots per workgroup (power of two)
 constexpr int TAB_PROBES = 16;
 constexpr uint32_t TAB_EMPTY = 0xffffffffu;
 
-// Workgroup-level aggregation of the gradient rows (LDS, 27 KB).
+// Workgroup-level aggregation of the vertex gradient rows (LDS, 37 KB).
 // Global float atomics execute at the memory side at ~20 G 64-byte requests/s chip-wide whatever they carry
 // (MI355X_MICROARCH.md, "Global float atomics"): with one request per (segment, row) -- 3 vertex rows + 1 face row
 // per list entry -- this kernel was bound by exactly that (0.195 ms with the atomics, 0.110 ms without, 0.195 ms
-// with one dword per row).  A workgroup walks a contiguous range of records, i.e. neighbouring entries of a few
-// tile lists, and those are neighbouring faces of the same surfaces: their vertex rows repeat (0.8 distinct rows
-// per entry over such a range, not 3).  So segment totals are first added into LDS tables keyed by row -- insertion
-// with ds_cmpst, sums with ds_add_f64 -- and a row goes to HBM once per workgroup.  The cells are DOUBLES for the
-// atomic's rate, not for precision: ds_add_f32 retires one lane per ~3 cycles per CU, ds_add_f64 ten times that
-// (scripts/micro/lds_atomics.hip); an earlier version elected a leader per row with plain LDS stores and had
-// followers ds_add_f32 onto it inside a 16-segment window (0.182 ms).  A full table or a long probe sequence
-// falls back to the direct atomics for that row.
+// with one dword per row).  A workgroup walks the records of ONE tile, i.e. the faces of a few surfaces crossing it,
+// whose vertex rows repeat (valence 6: ~0.6 distinct rows per entry over a tile, not 3).  So segment totals are first
+// added into an LDS table keyed by row -- insertion with ds_cmpst, sums with ds_add_f64 -- and a row goes to HBM once
+// per tile.  The cells are DOUBLES for the atomic's rate, not for precision: ds_add_f32 retires one lane per ~3 cycles
+// per CU, ds_add_f64 ten times that (scripts/micro/lds_atomics.hip).  A full table or a long probe sequence falls
+// back to the direct atomics for that row.  Face rows (opacity, intensity) are unique per (tile, face): a table cannot
+// merge anything but the partial sums of one entry, so they go out directly, one 8-byte request per segment tail.
 struct HitsLds {
+    float4 pix[2 * TILE_PIX];   // the tile's pixels: (ray direction, dL/ddepth), (dL/dcolor, -)
     float stage[4][STAGE_SEGS][STAGE_ROW];
-    uint32_t vkey[VTAB]; uint32_t fkey[FTAB];
+    uint32_t vkey[VTAB];
     double vval[VTAB][7];   // dx dy dz dr dg db ddepth of row (view, vertex)
-    double fval[FTAB][2];   // dopacity dintense of row (view, face)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -659,7 +692,7 @@ __device__ __forceinline__ int tab_find(uint32_t* __restrict__ key, uint32_t rid
 }
 
 // The n <= 16 segment totals a wave has just staged: lane (seg, w) adds row w of segment seg (w < 3: a vertex
-// row, w == 3: the face row) into the workgroup's tables.
+// row into the table, w == 3: the face row straight to HBM).
 __device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L, int wave, int lane, int n,
                                                   float* __restrict__ vrow, float* __restrict__ frow) {
     wave_lds_sync();  // the staged rows are visible to the whole wave
@@ -684,165 +717,172 @@ __device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L
             }
         } else {
             const uint32_t rid = (uint32_t)sb * (uint32_t)p.F + (uint32_t)__float_as_int(row[26]);
-            const int slot = (DMR_DBG(p, 2048) && (rid & 1u)) ? -1 : tab_find<FTAB>(L.fkey, rid);
-            if (slot >= 0) { atomicAdd(&L.fval[slot][0], (double)row[21]); atomicAdd(&L.fval[slot][1], (double)row[22]); }
-            else { atomicAdd(&frow[(int64_t)rid * FROW], row[21]); atomicAdd(&frow[(int64_t)rid * FROW + 1], row[22]); }
+            atomicAdd(&frow[(int64_t)rid * FROW], row[21]); atomicAdd(&frow[(int64_t)rid * FROW + 1], row[22]);
         }
     }
     wave_lds_sync();  // the stage area may be refilled
 }
 
+// One workgroup per tile (longest list first), one lane per GROUP of HIT_GROUP consecutive records -- all of one list
+// entry, because k_tri_backward_pix pads every face's run to a multiple of HIT_GROUP.  The lane gathers its face once,
+// sums the 23 components of its (up to) HIT_GROUP pairs in registers, and only then enters the segmented scan: one scan,
+// one tail hand-off per group instead of per record (the scan was 92 half-rate DPP instructions of ~600 per 64 records),
+// and HIT_GROUP independent pixel gathers in flight per lane.
 #ifdef DMR_HITS_WAVES
 __attribute__((amdgpu_waves_per_eu(DMR_HITS_WAVES, DMR_HITS_WAVES)))
 #endif
 __global__ void __launch_bounds__(256)
-k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits,
-                    const unsigned long long* __restrict__ hit_total, uint32_t capacity,
+k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits, uint32_t capacity,
                     float* __restrict__ vrow, float* __restrict__ frow) {
-    // all records; fewer only while a size guess is being refuted
-    const uint32_t first = 0u, nhits = (uint32_t)min((unsigned long long)capacity, *hit_total);
+    const int tile = (int)p.tile_order[blockIdx.x];
+    uint32_t nrec = p.tile_used[tile];
+    if (nrec == 0u) return;  // uniform: nothing blended in this tile (or outside this shard's band)
+    const uint32_t rec0 = p.hit_offset[tile];
+    // (fewer only while a size guess is being refuted / an asynchronous call overflowed: whole groups inside the buffer)
+    if (rec0 + ((nrec + (uint32_t)(HIT_BLOCK - 1)) & ~(uint32_t)(HIT_BLOCK - 1)) > capacity) return;  // the results are thrown away
+    const uint32_t ngroups = nrec / (uint32_t)HIT_GROUP;
+    const int b = tile / (p.gx * p.gy);
+
     __shared__ HitsLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t HW = (int64_t)p.H * p.W;
     for (int i = tid; i < VTAB; i += 256) {
         L.vkey[i] = TAB_EMPTY;
 #pragma unroll
         for (int c = 0; c < 7; c++) L.vval[i][c] = 0.0;
     }
-    for (int i = tid; i < FTAB; i += 256) { L.fkey[i] = TAB_EMPTY; L.fval[i][0] = 0.0; L.fval[i][1] = 0.0; }
+    L.pix[tid] = pixrec[2 * (int64_t)tile * TILE_PIX + tid];
+    L.pix[tid + 256] = pixrec[2 * (int64_t)tile * TILE_PIX + 256 + tid];
     __syncthreads();
-    // the workgroup owns a contiguous range of hit records (its waves consecutive quarters of it), so that the
-    // tables see neighbouring list entries
-    const uint32_t nwaves = gridDim.x * 4u, niter = (nhits - first + 63u) / 64u;
-    const uint32_t per_wave = (niter + nwaves - 1u) / nwaves;
-    const uint32_t it0 = min(niter, (blockIdx.x * 4u + (uint32_t)wave) * per_wave), it1 = min(niter, it0 + per_wave);
-    for (uint32_t it = it0; it < it1; it++) {
-        const uint32_t base = first + it * 64u;
-        const uint32_t hi_idx = base + lane;
-        HitRecord hr; hr.entry = 0u; hr.pixel = HIT_SKIPPED; hr.T = 0.f; hr.dL_dalpha = 0.f;
-        if (hi_idx < nhits) hr = hits[hi_idx];
-        const bool valid = hi_idx < nhits;                    // lanes past the end: no record, unique keys
-        const bool skipped = (hr.pixel & HIT_SKIPPED) != 0u;  // member of its entry's run, contributes nothing
-        hr.pixel &= ~HIT_SKIPPED;
+    const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
+
+    // record q of a lane's group: the wave's 64 lanes read one contiguous kilobyte (dmr_kernels.hpp, HIT_BLOCK).
+    // The four `id` words of a group are the face and its three vertices (k_tri_backward_pix), so the vertex data can
+    // be gathered as soon as the records are here: two dependent memory levels per round instead of four
+    // (record -> list entry -> face -> vertices) -- and the records of round r + 1 are loaded while round r computes.
+    auto load_group = [&](uint32_t gi, uint4 (&r)[HIT_GROUP]) {
+        const bool in = gi < ngroups;
+        const uint4* src = reinterpret_cast<const uint4*>(hits + rec0 + (uint64_t)((in ? gi : 0u) / 64u) * HIT_BLOCK + (uint32_t)lane);
+#pragma unroll
+        for (int q = 0; q < HIT_GROUP; q++) r[q] = in ? src[64 * q] : make_uint4(0u, HIT_SKIPPED, 0u, 0u);
+    };
+    uint4 raw[HIT_GROUP], nxt[HIT_GROUP];
+    load_group((uint32_t)tid, nxt);
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += 256u) {
+        const uint32_t gi = g0 + (uint32_t)tid;
+        const bool valid = gi < ngroups;   // lanes past the end: no group, unique keys
+#pragma unroll
+        for (int q = 0; q < HIT_GROUP; q++) raw[q] = nxt[q];
+        load_group(gi + 256u, nxt);  // in flight while this round computes (past the end: nothing is loaded)
         int k = -1 - lane;  // invalid lanes: unique keys
-        int v0 = 0, v1 = 0, v2 = 0, face = 0, b = 0;
+        int v0 = 0, v1 = 0, v2 = 0, face = 0;
         float g[NACC];
 #pragma unroll
         for (int c = 0; c < NACC; c++) g[c] = 0.f;
-        if (valid) {  // key and row ids: a skipped pair at the end of its run still carries the run's sums to the tables
-            k = (int)hr.entry;
-            face = (int)p.face_list[hr.entry];
-            b = (int)(hr.pixel / (uint32_t)HW);
-            v0 = p.faces[3 * face]; v1 = p.faces[3 * face + 1]; v2 = p.faces[3 * face + 2];
+        if (valid) {  // key and row ids: a group of skipped pairs at the end of its run still carries the run's sums to the tables
+            face = (int)raw[0].x; v0 = (int)raw[1].x; v1 = (int)raw[2].x; v2 = (int)raw[3].x;
+            k = face;  // a face occurs once per tile: as good a segment key as the list entry
         }
-        if (valid && !skipped) {
+        if (valid) {
             using namespace fm;
-            const float4 pr0 = pixrec[2 * (int64_t)hr.pixel], pr1 = pixrec[2 * (int64_t)hr.pixel + 1];
+            // the face, once per group
             const float alpha = p.faces_opacity[face], intense = p.faces_intense[(int64_t)b * p.F + face];
             const F3 cc0 = load3(p.verts_color, v0), cc1 = load3(p.verts_color, v1), cc2 = load3(p.verts_color, v2);
             const float fd0 = p.vproj[(int64_t)b * p.P + v0].w, fd1 = p.vproj[(int64_t)b * p.P + v1].w,
                         fd2 = p.vproj[(int64_t)b * p.P + v2].w;
-            // forward quantities of this (pixel, face) pair (backward.cu:206-243).  Exact arithmetic (the V3 helpers
-            // are not contracted): the clamp region `code` selects a piecewise-constant Jacobian, so (u, v) must land
-            // on the same side of the region borders as in the forward.
-            float iu, iv, denom, nu;
-            F3 d, Tv, E1, E2, Q, Pv;
-            {
+            const V3 xp0 = load_v3(p.verts, v0), xp1 = load_v3(p.verts, v1), xp2 = load_v3(p.verts, v2);
+            const V3 xT = view_o - xp0, xE1 = xp1 - xp0, xE2 = xp2 - xp0;
+            const V3 xQ = dmr::cross(xT, xE1);
+            const float w2 = dmr::dot(xQ, xE2);
+            const V3 xE12 = dmr::cross(xE1, xE2), xE2T = dmr::cross(xE2, xT);
+#pragma unroll
+            for (int q = 0; q < HIT_GROUP; q++) {
+                if (raw[q].y & HIT_SKIPPED) continue;  // pad, or a pair the forward skipped (denom == 0)
+                const float4 pr0 = L.pix[2 * (raw[q].y & 255u)], pr1 = L.pix[2 * (raw[q].y & 255u) + 1];
+                const float hT = __uint_as_float(raw[q].z), hdLda = __uint_as_float(raw[q].w);
+                // forward quantities of this (pixel, face) pair (backward.cu:206-243).  Exact arithmetic (the V3 helpers
+                // are not contracted): the clamp region `code` selects a piecewise-constant Jacobian, so (u, v) must land
+                // on the same side of the region borders as in the forward.
                 const V3 xd = {pr0.x, pr0.y, pr0.z};
-                const V3 xp0 = load_v3(p.verts, v0), xp1 = load_v3(p.verts, v1), xp2 = load_v3(p.verts, v2);
-                const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
-                const V3 xT = view_o - xp0, xE1 = xp1 - xp0, xE2 = xp2 - xp0;
-                const V3 xQ = dmr::cross(xT, xE1), xP = dmr::cross(xd, xE2);
-                denom = dmr::dot(xP, xE1);
+                const V3 xP = dmr::cross(xd, xE2);
+                const float denom = dmr::dot(xP, xE1);
                 const float inv_denom = 1.0f / denom;  // IEEE like the forward: a 1-ulp v_rcp_f32 flips the region of a
                                                        // (u, v) on a border now and then (4 vertices at C5's 376 M pairs)
-                nu = dmr::dot(xP, xT);
-                iu = nu * inv_denom;
-                iv = dmr::dot(xQ, xd) * inv_denom;
-                d = {xd.x, xd.y, xd.z}; Tv = {xT.x, xT.y, xT.z}; E1 = {xE1.x, xE1.y, xE1.z}; E2 = {xE2.x, xE2.y, xE2.z};
-                Q = {xQ.x, xQ.y, xQ.z}; Pv = {xP.x, xP.y, xP.z};
-            }
-            float iuc, ivc; int code;
-            clamp_bary_uv(iu, iv, iuc, ivc, code);
-            const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
-            // dL/dcolor and dL/ddepth of the pair (backward.cu:254-275), the face intensity folded in once
-            const float aT = alpha * hr.T;
-            const float dic0 = pr1.x * aT, dic1 = pr1.y * aT, dic2 = pr1.z * aT, did = pr0.w * aT;
-            const float dii0 = dic0 * intense, dii1 = dic1 * intense, dii2 = dic2 * intense;
-            // dL/d(barycentric weights) (backward.cu:313-330)
-            const float dL_di0 = cc0.x * dii0 + cc0.y * dii1 + cc0.z * dii2 + fd0 * did;
-            const float dL_di1 = cc1.x * dii0 + cc1.y * dii1 + cc1.z * dii2 + fd1 * did;
-            const float dL_di2 = cc2.x * dii0 + cc2.y * dii1 + cc2.z * dii2 + fd2 * did;
-            const float dfint = (i0 * cc0.x + i1 * cc1.x + i2 * cc2.x) * dic0 + (i0 * cc0.y + i1 * cc1.y + i2 * cc2.y) * dic1
-                              + (i0 * cc0.z + i1 * cc1.z + i2 * cc2.z) * dic2;
-            // through the clamp (i0 = 1 - uc - vc, i1 = uc, i2 = vc; Jacobian of auxiliary.h:374-400)
-            float duc_du, duc_dv, dvc_du, dvc_dv;
-            clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
-            const float e1 = dL_di1 - dL_di0, e2 = dL_di2 - dL_di0;
-            const float dL_diu = e1 * duc_du + e2 * dvc_du;
-            const float dL_div = e1 * duc_dv + e2 * dvc_dv;
-            // ray_tri_intersection_grad (auxiliary.h:288-333; Q11: the "v" numerator is t's, Q12: no clamp of
-            // denom^2) in the reference's own order of operations and without contraction (the V3 helpers): for a
-            // grazing ray 1 / denom^2 is huge and the six derivative vectors are differences of nearly equal terms,
-            // so this part stays bit-comparable with the oracle.  (A regrouped form with three scalars per hit saves
-            // ~30 instructions; the kernel is not bound by them.)
-            const float dinv = 1.0f / (denom * denom);
-            V3 dp0, dp1, dp2;
-            {
-                const V3 xP = {Pv.x, Pv.y, Pv.z}, xT = {Tv.x, Tv.y, Tv.z}, xE1 = {E1.x, E1.y, E1.z}, xE2 = {E2.x, E2.y, E2.z};
-                const V3 xQ = {Q.x, Q.y, Q.z}, xd = {d.x, d.y, d.z};
-                const float w0 = nu, w1 = denom, w2 = dmr::dot(xQ, xE2);
+                const float nu = dmr::dot(xP, xT);
+                const float iu = nu * inv_denom;
+                const float iv = dmr::dot(xQ, xd) * inv_denom;
+                float iuc, ivc; int code;
+                clamp_bary_uv(iu, iv, iuc, ivc, code);
+                const float i0 = 1 - iuc - ivc, i1 = iuc, i2 = ivc;
+                // dL/dcolor and dL/ddepth of the pair (backward.cu:254-275), the face intensity folded in once
+                const float aT = alpha * hT;
+                const float dic0 = pr1.x * aT, dic1 = pr1.y * aT, dic2 = pr1.z * aT, did = pr0.w * aT;
+                const float dii0 = dic0 * intense, dii1 = dic1 * intense, dii2 = dic2 * intense;
+                // dL/d(barycentric weights) (backward.cu:313-330)
+                const float dL_di0 = cc0.x * dii0 + cc0.y * dii1 + cc0.z * dii2 + fd0 * did;
+                const float dL_di1 = cc1.x * dii0 + cc1.y * dii1 + cc1.z * dii2 + fd1 * did;
+                const float dL_di2 = cc2.x * dii0 + cc2.y * dii1 + cc2.z * dii2 + fd2 * did;
+                const float dfint = (i0 * cc0.x + i1 * cc1.x + i2 * cc2.x) * dic0 + (i0 * cc0.y + i1 * cc1.y + i2 * cc2.y) * dic1
+                                  + (i0 * cc0.z + i1 * cc1.z + i2 * cc2.z) * dic2;
+                // through the clamp (i0 = 1 - uc - vc, i1 = uc, i2 = vc; Jacobian of auxiliary.h:374-400)
+                float duc_du, duc_dv, dvc_du, dvc_dv;
+                clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
+                const float e1 = dL_di1 - dL_di0, e2 = dL_di2 - dL_di0;
+                const float dL_diu = e1 * duc_du + e2 * dvc_du;
+                const float dL_div = e1 * duc_dv + e2 * dvc_dv;
+                // ray_tri_intersection_grad (auxiliary.h:288-333; Q11: the "v" numerator is t's, Q12: no clamp of
+                // denom^2) in the reference's own order of operations and without contraction (the V3 helpers): for a
+                // grazing ray 1 / denom^2 is huge and the six derivative vectors are differences of nearly equal terms,
+                // so this part stays bit-comparable with the oracle.
+                const float dinv = 1.0f / (denom * denom);
+                const float w0 = nu, w1 = denom;
                 const V3 du_dE1 = (-1.0f * xP * w0) * dinv;
                 const V3 du_dE2 = (dmr::cross(xT, xd) * w1 - w0 * dmr::cross(xE1, xd)) * dinv;
                 const V3 du_dT = (xP * w1) * dinv;
-                const V3 dv_dE1 = ((dmr::cross(xE2, xT) * w1) - (w2 * xP)) * dinv;
+                const V3 dv_dE1 = ((xE2T * w1) - (w2 * xP)) * dinv;
                 const V3 dv_dE2 = ((xQ * w1) - (w2 * dmr::cross(xE1, xd))) * dinv;
-                const V3 dv_dT = dmr::cross(xE1, xE2) * w1 * dinv;
+                const V3 dv_dT = xE12 * w1 * dinv;
                 const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
-                dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
-                dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
-                dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
-            }
-
-            g[0] = dp0.x; g[1] = dp0.y; g[2] = dp0.z;
-            g[3] = dp1.x; g[4] = dp1.y; g[5] = dp1.z;
-            g[6] = dp2.x; g[7] = dp2.y; g[8] = dp2.z;
-            g[9] = i0 * dii0; g[10] = i0 * dii1; g[11] = i0 * dii2;
-            g[12] = i1 * dii0; g[13] = i1 * dii1; g[14] = i1 * dii2;
-            g[15] = i2 * dii0; g[16] = i2 * dii1; g[17] = i2 * dii2;
-            g[18] = i0 * did; g[19] = i1 * did; g[20] = i2 * did;
-            g[21] = hr.dL_dalpha; g[22] = dfint;
-
-            // The scan below multiplies neighbours' partial sums by 0/1 masks, so a non-finite value must not enter
-            // it (0 * inf = NaN would leak into the next list entry).  Such a pair (degenerate face, Q12; opacity
-            // exactly 1 behind it) adds its values with plain atomics, as the reference does for every pair.
-            const float chk = (dinv * 0.f) + (aT * 0.f) + (hr.dL_dalpha * 0.f);
-            if (!(chk == 0.f)) {
-                float* r0 = vrow + ((int64_t)b * p.P + v0) * VROW; float* r1 = vrow + ((int64_t)b * p.P + v1) * VROW;
-                float* r2 = vrow + ((int64_t)b * p.P + v2) * VROW; float* rf = frow + ((int64_t)b * p.F + face) * FROW;
+                const V3 dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
+                const V3 dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
+                const V3 dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
+                float h[NACC];
+                h[0] = dp0.x; h[1] = dp0.y; h[2] = dp0.z;
+                h[3] = dp1.x; h[4] = dp1.y; h[5] = dp1.z;
+                h[6] = dp2.x; h[7] = dp2.y; h[8] = dp2.z;
+                h[9] = i0 * dii0; h[10] = i0 * dii1; h[11] = i0 * dii2;
+                h[12] = i1 * dii0; h[13] = i1 * dii1; h[14] = i1 * dii2;
+                h[15] = i2 * dii0; h[16] = i2 * dii1; h[17] = i2 * dii2;
+                h[18] = i0 * did; h[19] = i1 * did; h[20] = i2 * did;
+                h[21] = hdLda; h[22] = dfint;
+                // The scan below multiplies neighbours' partial sums by 0/1 masks, so a non-finite value must not enter
+                // it (0 * inf = NaN would leak into the next list entry).  Such a pair (degenerate face, Q12; opacity
+                // exactly 1 behind it) adds its values with plain atomics, as the reference does for every pair.
+                const float chk = (dinv * 0.f) + (aT * 0.f) + (hdLda * 0.f);
+                if (!(chk == 0.f)) {
+                    float* r0 = vrow + ((int64_t)b * p.P + v0) * VROW; float* r1 = vrow + ((int64_t)b * p.P + v1) * VROW;
+                    float* r2 = vrow + ((int64_t)b * p.P + v2) * VROW; float* rf = frow + ((int64_t)b * p.F + face) * FROW;
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    atomicAdd(r0 + c, g[c]); atomicAdd(r1 + c, g[3 + c]); atomicAdd(r2 + c, g[6 + c]);
-                    atomicAdd(r0 + 3 + c, g[9 + c]); atomicAdd(r1 + 3 + c, g[12 + c]); atomicAdd(r2 + 3 + c, g[15 + c]);
+                    for (int c = 0; c < 3; c++) {
+                        atomicAdd(r0 + c, h[c]); atomicAdd(r1 + c, h[3 + c]); atomicAdd(r2 + c, h[6 + c]);
+                        atomicAdd(r0 + 3 + c, h[9 + c]); atomicAdd(r1 + 3 + c, h[12 + c]); atomicAdd(r2 + 3 + c, h[15 + c]);
+                    }
+                    atomicAdd(r0 + 6, h[18]); atomicAdd(r1 + 6, h[19]); atomicAdd(r2 + 6, h[20]);
+                    atomicAdd(rf, h[21]); atomicAdd(rf + 1, h[22]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NACC; c++) g[c] += h[c];
                 }
-                atomicAdd(r0 + 6, g[18]); atomicAdd(r1 + 6, g[19]); atomicAdd(r2 + 6, g[20]);
-                atomicAdd(rf, g[21]); atomicAdd(rf + 1, g[22]);
-#pragma unroll
-                for (int c = 0; c < NACC; c++) g[c] = 0.f;
-                // (k stays the entry: like a skipped pair, the lane remains a member of its run with zero sums)
             }
         }
-        // segmented inclusive scan over the wave (hits of one entry are consecutive lanes): four row-local
-        // DPP levels, then the two row-broadcast levels of the classic wave scan
+        // segmented inclusive scan over the wave (groups of one entry are consecutive lanes): four row-local DPP levels.
+        // The scan stops at the 16-lane DPP rows: the table takes partial sums just as well, so an entry that crosses a
+        // row boundary simply contributes one more partial.
         seg_scan_level<DPP_ROW_SHR + 1, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 2, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 4, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 8, 0xF>(k, g);
-        // The scan stops at the 16-lane DPP rows: the tables below take partial sums just as well, so an entry that
-        // crosses a row boundary simply contributes one more partial (the two row-broadcast levels cost 46 VALU
-        // per round; the extra partials ride in lanes that were idle anyway).
 
-        // segment tails hold the totals: stage them (wave-private LDS), 16 at a time, and add them into the tables
+        // segment tails hold the totals: stage them (wave-private LDS), 16 at a time, and add them into the table
         const int kn = __shfl_down(k, 1, 64);
         const bool tail = valid && ((lane & 15) == 15 || kn != k);
         const uint64_t tmask = __ballot(tail);
@@ -859,18 +899,13 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             if (!DMR_DBG(p, 512)) accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
         }
     }
-    // every row of the tables goes out once: 8 lanes per vertex row (7 used), 2 lanes per face row
+    // every row of the table goes out once: 8 lanes per vertex row (7 used)
     __syncthreads();
     if (DMR_DBG(p, 1024)) return;
     for (int s0 = 0; s0 < VTAB; s0 += 32) {
         const int slot = s0 + (tid >> 3), comp = tid & 7;
         const uint32_t rid = L.vkey[slot];
         if (rid != TAB_EMPTY && comp < 7) atomicAdd(&vrow[(int64_t)rid * VROW + comp], (float)L.vval[slot][comp]);
-    }
-    for (int s0 = 0; s0 < FTAB; s0 += 128) {
-        const int slot = s0 + (tid >> 1), comp = tid & 1;
-        const uint32_t rid = L.fkey[slot];
-        if (rid != TAB_EMPTY) atomicAdd(&frow[(int64_t)rid * FROW + comp], (float)L.fval[slot][comp]);
     }
 }
 
@@ -915,7 +950,7 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
-    p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset; p.tile_order = img.tile_order;
+    p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset; p.tile_used = img.tile_used; p.tile_order = img.tile_order;
     p.list_capacity = 0xffffffffu;
     return p;
 }
@@ -941,18 +976,13 @@ void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1,
                                                                             work, (uint32_t)work_floats);
 }
 
-void launch_tri_backward_hits(const dmr_scene& s, const float4* vproj, const uint32_t* face_list,
-                              const float4* pixrec, const HitRecord* hits, const unsigned long long* hit_total,
-                              uint32_t capacity, float* vrow, float* frow, hipStream_t st) {
+void launch_tri_backward_hits(const dmr_scene& s, int gx, int gy, const float4* vproj, const uint32_t* face_list, TriImageState img,
+                              const float4* pixrec, const HitRecord* hits, uint32_t capacity, float* vrow, float* frow,
+                              hipStream_t st) {
     if (capacity == 0) return;
-    TriImageState none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    TriParams p = make_params(s, 0, 0, 0, 0, vproj, nullptr, face_list, none);
-    // grid from the host-known bound; >= 8 rounds of 64 records per wave
-    // one workgroup per DMR_HITS_PER_BLOCK records: the LDS tables are sized for that range (a longer one overflows
-    // them into the direct-atomic fallback: 14.7 ms instead of ~4 at C5 when the grid was capped)
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)capacity + DMR_HITS_PER_BLOCK - 1) / DMR_HITS_PER_BLOCK, 0x7fffffffu);
+    TriParams p = make_params(s, gx, gy, 0, 0, vproj, nullptr, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
-    k_tri_backward_hits<<<dim3(std::max(1u, blocks)), dim3(256), 0, st>>>(p, pixrec, hits, hit_total, capacity, vrow, frow);
+    k_tri_backward_hits<<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, pixrec, hits, capacity, vrow, frow);
 }
 
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,
