@@ -1,0 +1,25 @@
+# usage: bash scripts/prof_shard.sh <outdir-name> ; rocprofv3 kernel traces of ONE rank's work when C4 is sharded 1 / 2 / 8 ways
+# (bench.py --emulate-rank R/N: the rank's tile-row band, one process, no collective) -> kernel sums per rank
+set -e
+OUT=gpurun_out/$1
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for spec in 0/1 0/2 1/2 0/8 3/8 7/8; do
+  tag=$(echo $spec | tr / _)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 bench.py --emulate-rank $spec --steps 30 --warmup 5 > $OUT/bench_$tag.json 2> $OUT/trace_$tag.err || true
+  cp $OUT/trace_$tag/*/*_kernel_stats.csv $OUT/kernel_stats_rank_$tag.csv
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, json, sys
+out = sys.argv[1]
+res = {}
+for f in sorted(glob.glob(f"{out}/kernel_stats_rank_*.csv")):
+    tag = f.split("rank_")[1][:-4]
+    rows = [r for r in csv.DictReader(open(f)) if "dmr::" in r["Name"]]
+    per = {r["Name"].split("(")[0].replace("void ", "").replace("dmr::", "").split("<")[0]: round(float(r["AverageNs"]) / 1000, 1) for r in rows}
+    b = json.load(open(f"{out}/bench_{tag}.json"))
+    res[tag] = {"kernel_sum_us": round(sum(per.values()), 1), "ms_per_step": b["ms_per_step"], "band": b["config"]["parallelism"], "kernels_us": per}
+    print(tag, res[tag]["kernel_sum_us"], "us kernels;", b["ms_per_step"], "ms/step;", per)
+json.dump(res, open(f"{out}/shard_kernel_sums.json", "w"), indent=1)
+PY
