@@ -667,8 +667,13 @@ constexpr uint32_t TAB_EMPTY = 0xffffffffu;
 // per CU, ds_add_f64 ten times that (scripts/micro/lds_atomics.hip).  A full table or a long probe sequence falls
 // back to the direct atomics for that row.  Face rows (opacity, intensity) are unique per (tile, face): a table cannot
 // merge anything but the partial sums of one entry, so they go out directly, one 8-byte request per segment tail.
+#ifndef DMR_HITS_PIX_LDS
+#define DMR_HITS_PIX_LDS 1
+#endif
 struct HitsLds {
+#if DMR_HITS_PIX_LDS
     float4 pix[2 * TILE_PIX];   // the tile's pixels: (ray direction, dL/ddepth), (dL/dcolor, -)
+#endif
     float stage[4][STAGE_SEGS][STAGE_ROW];
     uint32_t vkey[VTAB];
     double vval[VTAB][7];   // dx dy dz dr dg db ddepth of row (view, vertex)
@@ -728,10 +733,10 @@ __device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L
 // sums the 23 components of its (up to) HIT_GROUP pairs in registers, and only then enters the segmented scan: one scan,
 // one tail hand-off per group instead of per record (the scan was 92 half-rate DPP instructions of ~600 per 64 records),
 // and HIT_GROUP independent pixel gathers in flight per lane.
-#ifdef DMR_HITS_WAVES
-__attribute__((amdgpu_waves_per_eu(DMR_HITS_WAVES, DMR_HITS_WAVES)))
+#ifndef DMR_HITS_WAVES
+#define DMR_HITS_WAVES 1
 #endif
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DMR_HITS_WAVES)
 k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits, uint32_t capacity,
                     float* __restrict__ vrow, float* __restrict__ frow) {
     const int tile = (int)p.tile_order[blockIdx.x];
@@ -750,8 +755,10 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
 #pragma unroll
         for (int c = 0; c < 7; c++) L.vval[i][c] = 0.0;
     }
+#if DMR_HITS_PIX_LDS
     L.pix[tid] = pixrec[2 * (int64_t)tile * TILE_PIX + tid];
     L.pix[tid + 256] = pixrec[2 * (int64_t)tile * TILE_PIX + 256 + tid];
+#endif
     __syncthreads();
     const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
 
@@ -797,7 +804,12 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
 #pragma unroll
             for (int q = 0; q < HIT_GROUP; q++) {
                 if (raw[q].y & HIT_SKIPPED) continue;  // pad, or a pair the forward skipped (denom == 0)
+#if DMR_HITS_PIX_LDS
                 const float4 pr0 = L.pix[2 * (raw[q].y & 255u)], pr1 = L.pix[2 * (raw[q].y & 255u) + 1];
+#else
+                const float4* tp = pixrec + 2 * ((int64_t)tile * TILE_PIX + (raw[q].y & 255u));
+                const float4 pr0 = tp[0], pr1 = tp[1];
+#endif
                 const float hT = __uint_as_float(raw[q].z), hdLda = __uint_as_float(raw[q].w);
                 // forward quantities of this (pixel, face) pair (backward.cu:206-243).  Exact arithmetic (the V3 helpers
                 // are not contracted): the clamp region `code` selects a piecewise-constant Jacobian, so (u, v) must land
