@@ -633,13 +633,15 @@ k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, const uint32_t* __res
 
 // ---------------------------------------------------------------------------
 // 5. per-tile sort by (depth_bits, face_id).  One 256-thread workgroup per (view, tile).
-//    Normalised bitonic network (every compare-exchange ascending): with the segment
-//    virtually padded by +inf to a power of two, exchanges whose upper index is >= n are
-//    no-ops, so any n works without padding storage.  n <= SORT_LDS_KEYS runs in LDS;
-//    longer segments run the same network in place in global memory.
+//    n <= SORT_LDS_KEYS: segmented rank sort + merge by binary search, in LDS; longer segments: a normalised bitonic network (every compare-exchange ascending: with the segment virtually padded by
+//    +inf to a power of two, exchanges whose upper index is >= n are no-ops, so any n works without padding storage)
+//    in place in global memory.
 // ---------------------------------------------------------------------------
 constexpr int SORT_LDS_KEYS = 2048;  // 16 KiB: 8 workgroups per CU
-constexpr uint32_t RANK_SORT_MAX = 512;
+#ifndef DMR_SORT_SEG
+#define DMR_SORT_SEG 128
+#endif
+constexpr int SORT_SEG = DMR_SORT_SEG;  // keys per rank-sorted segment (two per lane)
 
 template <class Ptr>
 __device__ __forceinline__ void bitonic_pass(Ptr a, uint32_t n, uint32_t npow2, uint32_t tid, uint32_t nthreads, bool global_mem) {
@@ -670,31 +672,11 @@ __device__ __forceinline__ void bitonic_pass(Ptr a, uint32_t n, uint32_t npow2, 
     }
 }
 
-// Rank sort of one short segment (n <= RANK_SORT_MAX): keys are unique, so the number of smaller keys is the
-// output slot.  Lane l holds keys l, l + 64, ... (K per lane); wave w streams quarter w of the n keys as LDS
-// broadcasts (one ds_read_b64 serves K compares) and adds its partial ranks into s_rank with integer LDS atomics.
-template <int K>
-__device__ __forceinline__ void rank_quarter(const uint64_t* __restrict__ sk, uint32_t n, uint32_t lane, uint32_t j0,
-                                             uint32_t j1, uint32_t* __restrict__ s_rank) {
-    uint64_t k[K]; uint32_t r[K];
-#pragma unroll
-    for (int q = 0; q < K; q++) { const uint32_t e = lane + 64u * q; k[q] = e < n ? sk[e] : ~0ull; r[q] = 0u; }
-#pragma unroll 8
-    for (uint32_t j = j0; j < j1; j++) {
-        const uint64_t kj = sk[j];
-#pragma unroll
-        for (int q = 0; q < K; q++) r[q] += kj < k[q] ? 1u : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < K; q++)
-        if (lane + 64u * q < n && r[q]) atomicAdd(&s_rank[lane + 64u * q], r[q]);
-}
-
 __global__ void __launch_bounds__(256)
 k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_order,
              uint64_t* __restrict__ keys, uint32_t* __restrict__ face_list, uint32_t capacity) {
     __shared__ uint64_t s_keys[SORT_LDS_KEYS];
-    __shared__ uint32_t s_rank[RANK_SORT_MAX];
+    __shared__ uint32_t s_rank[SORT_LDS_KEYS];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // grid-stride over tiles: most tiles of a frame are empty, a workgroup launch per tile costs more than the sort
     for (uint32_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
@@ -704,38 +686,68 @@ k_sort_tiles(uint32_t ntiles, const uint32_t* __restrict__ tile_offset, const ui
     // (a segment beyond the buffer exists only while a size guess is being refuted: everything is redone then)
     if (n == 0 || end > capacity) continue;
     __syncthreads();  // the previous tile's keys are no longer needed
-    uint32_t npow2 = 1;
-    while (npow2 < n) npow2 <<= 1;
-    if (n <= RANK_SORT_MAX) {
-        // Short segments (the common case: C4 averages 315 entries per busy tile).  The first version gave every
-        // thread one or two keys and had it loop over all n keys: 4 n LDS reads and 8 n compares per tile.  Here
-        // n reads and K n compares per tile, split four ways.
-        for (uint32_t i = tid; i < n; i += 256) s_keys[i] = keys[begin + i];
-        for (uint32_t i = tid; i < n; i += 256) s_rank[i] = 0u;
-        __syncthreads();
-        const uint32_t per = (n + 3u) / 4u, j0 = min(n, wave * per), j1 = min(n, j0 + per);
-        const uint32_t kk = (n + 63u) / 64u;  // keys per lane, rounded up to an instantiated count
-        if (kk <= 1) rank_quarter<1>(s_keys, n, lane, j0, j1, s_rank);
-        else if (kk <= 2) rank_quarter<2>(s_keys, n, lane, j0, j1, s_rank);
-        else if (kk <= 3) rank_quarter<3>(s_keys, n, lane, j0, j1, s_rank);
-        else if (kk <= 4) rank_quarter<4>(s_keys, n, lane, j0, j1, s_rank);
-        else if (kk <= 6) rank_quarter<6>(s_keys, n, lane, j0, j1, s_rank);
-        else if (kk <= 8) rank_quarter<8>(s_keys, n, lane, j0, j1, s_rank);
-        else if (kk <= 12) rank_quarter<12>(s_keys, n, lane, j0, j1, s_rank);
-        else rank_quarter<16>(s_keys, n, lane, j0, j1, s_rank);
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += 256) face_list[begin + s_rank[i]] = (uint32_t)s_keys[i];  // nothing reads the sorted keys
-    } else if (n <= SORT_LDS_KEYS) {
+    if (n <= SORT_LDS_KEYS) {
+        // Segmented rank sort + merge.  Keys are unique, so a key's output slot is the number of smaller keys.  The n keys
+        // are cut into S segments of SORT_SEG = 128; wave w rank-sorts segments w, w + 4, ... on its own (lane l holds keys
+        // l and l + 64 of the segment and streams all of it as LDS broadcasts: len reads, 2 len compares per lane); the
+        // segments are then rewritten in sorted order, and every key adds to its rank in its own segment the number of
+        // smaller keys in each other segment -- a 7-step binary search.  Work: n * 128 compares + (S - 1) * 7 reads per key,
+        // against n^2 compares of one rank sort over the tile (C4's tiles average 315 keys, the longest 642; history: every
+        // thread looping over all keys 48 us; one rank sort per tile, split over the four waves, 24 us; tiles above 512 keys
+        // took a bitonic network in LDS, ~55 barrier-separated stages).
+        const uint32_t S = (n + SORT_SEG - 1u) / SORT_SEG;
         for (uint32_t i = tid; i < n; i += 256) s_keys[i] = keys[begin + i];
         __syncthreads();
-        bitonic_pass(s_keys, n, npow2, tid, 256, false);
-        for (uint32_t i = tid; i < n; i += 256) {
-            uint64_t k = s_keys[i];
-            keys[begin + i] = k;
-            face_list[begin + i] = (uint32_t)k;
+        for (uint32_t sg = wave; sg < S; sg += 4u) {
+            const uint32_t b0 = sg * SORT_SEG, len = min((uint32_t)SORT_SEG, n - b0);
+            const uint64_t k0 = lane < len ? s_keys[b0 + lane] : ~0ull, k1 = lane + 64u < len ? s_keys[b0 + lane + 64u] : ~0ull;
+            uint32_t r0 = 0u, r1 = 0u;
+#pragma unroll 8
+            for (uint32_t j = 0; j < len; j++) {
+                const uint64_t kj = s_keys[b0 + j];
+                r0 += kj < k0 ? 1u : 0u; r1 += kj < k1 ? 1u : 0u;
+            }
+            if (lane < len) s_rank[b0 + lane] = r0;
+            if (lane + 64u < len) s_rank[b0 + lane + 64u] = r1;
+        }
+        __syncthreads();
+        // every segment sorted in place (through registers: a thread holds at most 8 keys)
+        uint64_t mk[SORT_LDS_KEYS / 256]; uint32_t mr[SORT_LDS_KEYS / 256];
+#pragma unroll
+        for (int q = 0; q < SORT_LDS_KEYS / 256; q++) {
+            const uint32_t i = tid + 256u * q;
+            mk[q] = i < n ? s_keys[i] : 0ull; mr[q] = i < n ? s_rank[i] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SORT_LDS_KEYS / 256; q++) {
+            const uint32_t i = tid + 256u * q;
+            if (i < n) s_keys[(i & ~(uint32_t)(SORT_SEG - 1)) + mr[q]] = mk[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SORT_LDS_KEYS / 256; q++) {
+            const uint32_t i = tid + 256u * q;
+            if (i >= n) continue;
+            const uint64_t key = s_keys[i];
+            const uint32_t own = i / SORT_SEG;
+            uint32_t rank = i - own * SORT_SEG;
+            for (uint32_t sg = 0; sg < S; sg++) {
+                if (sg == own) continue;
+                const uint32_t b0 = sg * SORT_SEG;
+                uint32_t lo = 0, hi = min((uint32_t)SORT_SEG, n - b0);  // lower bound of `key` in the sorted segment
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_keys[b0 + mid] < key) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            face_list[begin + rank] = (uint32_t)key;  // nothing reads the sorted keys
         }
     } else {
         uint64_t* g = keys + begin;
+        uint32_t npow2 = 1;
+        while (npow2 < n) npow2 <<= 1;
         bitonic_pass(g, n, npow2, tid, 256, true);
         for (uint32_t i = tid; i < n; i += 256) face_list[begin + i] = (uint32_t)g[i];
     }
