@@ -239,7 +239,8 @@ at::TensorOptions f32_on(c10::Device dev) { return at::TensorOptions().dtype(at:
 
 // ---- the four functions of ext.cpp:6-11 -----------------------------------------------------------------------------
 // -> (num_rendered:int, color [B,3,H,W], depth [B,1,H,W], pointBuffer, faceBuffer, binningBuffer, imgBuffer)
-py::tuple render_tris(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
+using TriFwdOut = std::tuple<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>;
+TriFwdOut render_tris(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
                       const at::Tensor& faces_opacity, const at::Tensor& mv_mats, const at::Tensor& proj_mats,
                       const at::Tensor& inv_mv_mats, const at::Tensor& inv_proj_mats, const at::Tensor& verts_depth,
                       const at::Tensor& faces_intense, int64_t image_height, int64_t image_width, std::pair<int, int> rows,
@@ -256,19 +257,16 @@ py::tuple render_tris(const at::Tensor& background, const at::Tensor& verts, con
     at::Tensor color = full ? at::empty({call.sc.B, NUM_CHANNELS, image_height, image_width}, opt)
                             : at::zeros({call.sc.B, NUM_CHANNELS, image_height, image_width}, opt);
     at::Tensor depth = full ? at::empty({call.sc.B, 1, image_height, image_width}, opt) : at::zeros({call.sc.B, 1, image_height, image_width}, opt);
-    int rendered = 0, rc;
-    void* st = call.stream();
-    {
-        py::gil_scoped_release nogil;  // the default call waits for the size read-back; other Python threads may run
-        rc = g_abi.tri_forward(&call.sc, mptr<float>(color), mptr<float>(depth), &alloc_cb, &call.scratch, st, &rendered);
-    }
-    if (rc) raise_lib();
-    return py::make_tuple(rendered, color, depth, call.scratch.get(DMR_BUF_POINT), call.scratch.get(DMR_BUF_FACE),
+    int rendered = 0;
+    // (the bindings release the GIL around this whole function: the default call waits for the size read-back)
+    if (g_abi.tri_forward(&call.sc, mptr<float>(color), mptr<float>(depth), &alloc_cb, &call.scratch, call.stream(), &rendered)) raise_lib();
+    return TriFwdOut((int64_t)rendered, color, depth, call.scratch.get(DMR_BUF_POINT), call.scratch.get(DMR_BUF_FACE),
                           call.scratch.get(DMR_BUF_BINNING), call.scratch.get(DMR_BUF_IMAGE));
 }
 
 // -> (dL_dverts [P,3], dL_dvcolor [P,3], dL_dfopacity [F], dL_dvdepth [B,P], dL_dfintense [B,F])
-py::tuple render_tris_backward(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
+using TriBwdOut = std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>;
+TriBwdOut render_tris_backward(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
                                const at::Tensor& faces_opacity, const at::Tensor& mv_mats, const at::Tensor& proj_mats,
                                const at::Tensor& inv_mv_mats, const at::Tensor& inv_proj_mats, const at::Tensor& verts_depth,
                                const at::Tensor& faces_intense, const at::Tensor& dL_dout_color, const at::Tensor& dL_dout_depth,
@@ -302,16 +300,11 @@ py::tuple render_tris_backward(const at::Tensor& background, const at::Tensor& v
         g_fint = flat.narrow(0, o, B * F).view({B, F});
     }
     const at::Tensor pb = pointBuffer.contiguous(), fb = faceBuffer.contiguous(), bb = binningBuffer.contiguous(), ib = imageBuffer.contiguous();
-    int rc;
-    void* st = call.stream();
-    {
-        py::gil_scoped_release nogil;
-        rc = g_abi.tri_backward(&call.sc, mptr<const float>(gc), mptr<const float>(gd), (int)R, mptr<const void>(pb), mptr<const void>(fb),
-                                mptr<const void>(bb), mptr<const void>(ib), mptr<float>(g_verts), mptr<float>(g_vcolor), mptr<float>(g_fop),
-                                mptr<float>(g_vdepth), mptr<float>(g_fint), &alloc_cb, &call.scratch, st);
-    }
-    if (rc) raise_lib();
-    return py::make_tuple(g_verts, g_vcolor, g_fop, g_vdepth, g_fint);
+    if (g_abi.tri_backward(&call.sc, mptr<const float>(gc), mptr<const float>(gd), (int)R, mptr<const void>(pb), mptr<const void>(fb),
+                           mptr<const void>(bb), mptr<const void>(ib), mptr<float>(g_verts), mptr<float>(g_vcolor), mptr<float>(g_fop),
+                           mptr<float>(g_vdepth), mptr<float>(g_fint), &alloc_cb, &call.scratch, call.stream()))
+        raise_lib();
+    return TriBwdOut(g_verts, g_vcolor, g_fop, g_vdepth, g_fint);
 }
 
 void check_tets(const at::Tensor& faces, const at::Tensor& tets, const at::Tensor& face_tets, const at::Tensor& tet_faces) {
@@ -322,7 +315,8 @@ void check_tets(const at::Tensor& faces, const at::Tensor& tets, const at::Tenso
 }
 
 // -> (color [B,3,H,W], depth [B,1,H,W], active f32 [B,H,W], pointBuffer, faceBuffer, binningBuffer, imgBuffer)
-py::tuple render_tets(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
+using TetFwdOut = std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>;
+TetFwdOut render_tets(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
                       const at::Tensor& faces_opacity, const at::Tensor& mv_mats, const at::Tensor& proj_mats,
                       const at::Tensor& inv_mv_mats, const at::Tensor& inv_proj_mats, const at::Tensor& verts_depth,
                       const at::Tensor& faces_intense, const at::Tensor& tets, const at::Tensor& face_tets, const at::Tensor& tet_faces,
@@ -341,19 +335,16 @@ py::tuple render_tets(const at::Tensor& background, const at::Tensor& verts, con
     at::Tensor color = img({call.sc.B, NUM_CHANNELS, image_height, image_width});
     at::Tensor depth = img({call.sc.B, 1, image_height, image_width});
     at::Tensor active = img({call.sc.B, image_height, image_width});
-    int rendered = 0, rc;
-    void* st = call.stream();
-    {
-        py::gil_scoped_release nogil;
-        rc = g_abi.tet_forward(&call.sc, mptr<float>(color), mptr<float>(depth), mptr<float>(active), &alloc_cb, &call.scratch, st, &rendered);
-    }
-    if (rc) raise_lib();
-    return py::make_tuple(color, depth, active, call.scratch.get(DMR_BUF_POINT), call.scratch.get(DMR_BUF_FACE),
+    int rendered = 0;
+    if (g_abi.tet_forward(&call.sc, mptr<float>(color), mptr<float>(depth), mptr<float>(active), &alloc_cb, &call.scratch, call.stream(), &rendered))
+        raise_lib();
+    return TetFwdOut(color, depth, active, call.scratch.get(DMR_BUF_POINT), call.scratch.get(DMR_BUF_FACE),
                           call.scratch.get(DMR_BUF_BINNING), call.scratch.get(DMR_BUF_IMAGE));
 }
 
 // -> (dL_dverts_color [P,3], dL_dfaces_opacity [F])
-py::tuple render_tets_backward(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
+using TetBwdOut = std::tuple<at::Tensor, at::Tensor>;
+TetBwdOut render_tets_backward(const at::Tensor& background, const at::Tensor& verts, const at::Tensor& faces, const at::Tensor& verts_color,
                                const at::Tensor& faces_opacity, const at::Tensor& mv_mats, const at::Tensor& proj_mats,
                                const at::Tensor& inv_mv_mats, const at::Tensor& inv_proj_mats, const at::Tensor& verts_depth,
                                const at::Tensor& faces_intense, const at::Tensor& tets, const at::Tensor& face_tets,
@@ -379,16 +370,11 @@ py::tuple render_tets_backward(const at::Tensor& background, const at::Tensor& v
         g_vcolor = flat.narrow(0, 0, 3 * P).view({P, 3}); g_fop = flat.narrow(0, 3 * P, F);
     }
     const at::Tensor pb = pointBuffer.contiguous(), fb = faceBuffer.contiguous(), bb = binningBuffer.contiguous(), ib = imageBuffer.contiguous();
-    int rc;
-    void* st = call.stream();
-    {
-        py::gil_scoped_release nogil;
-        rc = g_abi.tet_backward(&call.sc, mptr<const float>(gc), mptr<const float>(gd), mptr<const void>(pb), mptr<const void>(fb),
-                                mptr<const void>(bb), mptr<const void>(ib), mptr<float>(g_vcolor), mptr<float>(g_fop), &alloc_cb,
-                                &call.scratch, st);
-    }
-    if (rc) raise_lib();
-    return py::make_tuple(g_vcolor, g_fop);
+    if (g_abi.tet_backward(&call.sc, mptr<const float>(gc), mptr<const float>(gd), mptr<const void>(pb), mptr<const void>(fb),
+                           mptr<const void>(bb), mptr<const void>(ib), mptr<float>(g_vcolor), mptr<float>(g_fop), &alloc_cb,
+                           &call.scratch, call.stream()))
+        raise_lib();
+    return TetBwdOut(g_vcolor, g_fop);
 }
 
 // ---- extensions -----------------------------------------------------------------------------------------------------
@@ -455,21 +441,22 @@ PYBIND11_MODULE(_C, m) {
     m.def("render_tris", &render_tris, py::arg("background"), py::arg("verts"), py::arg("faces"), py::arg("verts_color"),
           py::arg("faces_opacity"), py::arg("mv_mats"), py::arg("proj_mats"), py::arg("inv_mv_mats"), py::arg("inv_proj_mats"),
           py::arg("verts_depth"), py::arg("faces_intense"), py::arg("image_height"), py::arg("image_width"),
-          py::arg("rows") = no_rows, py::arg("fill_outside") = true);
+          py::arg("rows") = no_rows, py::arg("fill_outside") = true, py::call_guard<py::gil_scoped_release>());
     m.def("render_tris_backward", &render_tris_backward, py::arg("background"), py::arg("verts"), py::arg("faces"), py::arg("verts_color"),
           py::arg("faces_opacity"), py::arg("mv_mats"), py::arg("proj_mats"), py::arg("inv_mv_mats"), py::arg("inv_proj_mats"),
           py::arg("verts_depth"), py::arg("faces_intense"), py::arg("dL_dout_color"), py::arg("dL_dout_depth"), py::arg("R"),
           py::arg("pointBuffer"), py::arg("faceBuffer"), py::arg("binningBuffer"), py::arg("imageBuffer"),
-          py::arg("rows") = no_rows, py::arg("flat_out") = py::none());
+          py::arg("rows") = no_rows, py::arg("flat_out") = py::none(), py::call_guard<py::gil_scoped_release>());
     m.def("render_tets", &render_tets, py::arg("background"), py::arg("verts"), py::arg("faces"), py::arg("verts_color"),
           py::arg("faces_opacity"), py::arg("mv_mats"), py::arg("proj_mats"), py::arg("inv_mv_mats"), py::arg("inv_proj_mats"),
           py::arg("verts_depth"), py::arg("faces_intense"), py::arg("tets"), py::arg("face_tets"), py::arg("tet_faces"),
-          py::arg("image_height"), py::arg("image_width"), py::arg("ray_random_seed"), py::arg("rows") = no_rows);
+          py::arg("image_height"), py::arg("image_width"), py::arg("ray_random_seed"), py::arg("rows") = no_rows,
+          py::call_guard<py::gil_scoped_release>());
     m.def("render_tets_backward", &render_tets_backward, py::arg("background"), py::arg("verts"), py::arg("faces"), py::arg("verts_color"),
           py::arg("faces_opacity"), py::arg("mv_mats"), py::arg("proj_mats"), py::arg("inv_mv_mats"), py::arg("inv_proj_mats"),
           py::arg("verts_depth"), py::arg("faces_intense"), py::arg("tets"), py::arg("face_tets"), py::arg("tet_faces"),
           py::arg("grad_color"), py::arg("grad_depth"), py::arg("pointBuffer"), py::arg("faceBuffer"), py::arg("binningBuffer"),
-          py::arg("imageBuffer"), py::arg("rows") = no_rows, py::arg("flat_out") = py::none());
+          py::arg("imageBuffer"), py::arg("rows") = no_rows, py::arg("flat_out") = py::none(), py::call_guard<py::gil_scoped_release>());
     m.def("invert_mats", &invert_mats);
     m.def("export", &export_item, py::arg("name"), py::arg("call_args"), py::arg("is_tet"), py::arg("num_rendered"), py::arg("buffers"),
           py::arg("H"), py::arg("W"), py::arg("dtype"));
