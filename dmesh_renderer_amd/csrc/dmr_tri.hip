@@ -36,6 +36,29 @@ constexpr int FWD_CHUNK = 128;
 #endif
 constexpr int BWD_CHUNK = DMR_BWD_CHUNK;
 
+// Phase stamps (ablation build only, DMR_ABLATE bit 4096; scripts/phase_times.py reads them): lane 0 of every wave of the
+// first PH_BLOCKS workgroups (= the longest tile lists, tile_order) writes s_memtime at the phase boundaries of its first
+// PH_CHUNKS chunks / rounds, and wave 0 the 100 MHz s_memrealtime at both ends of the workgroup.  This is how "where does a
+// tile's serial chain spend its time" is measured instead of guessed.
+#ifdef DMR_ABLATION
+constexpr int PH_KERNELS = 3, PH_BLOCKS = 3072, PH_CHUNKS = 6, PH_STAMPS = 10;
+__device__ unsigned long long g_phase[PH_KERNELS][PH_BLOCKS][4][PH_CHUNKS][PH_STAMPS];
+__device__ unsigned long long g_phase_rt[PH_KERNELS][PH_BLOCKS][2];
+#define DMR_STAMP(p, kern, chunk, s)                                                                              \
+    do {                                                                                                          \
+        if (DMR_DBG(p, 4096) && (threadIdx.x & 63) == 0 && blockIdx.x < PH_BLOCKS && (chunk) < (uint32_t)PH_CHUNKS) \
+            g_phase[kern][blockIdx.x][threadIdx.x >> 6][chunk][s] = __builtin_amdgcn_s_memtime();                 \
+    } while (0)
+#define DMR_STAMP_RT(p, kern, e)                                                                                  \
+    do {                                                                                                          \
+        if (DMR_DBG(p, 4096) && threadIdx.x == 0 && blockIdx.x < PH_BLOCKS)                                        \
+            g_phase_rt[kern][blockIdx.x][e] = __builtin_amdgcn_s_memrealtime();                                   \
+    } while (0)
+#else
+#define DMR_STAMP(p, kern, chunk, s) do {} while (0)
+#define DMR_STAMP_RT(p, kern, e) do {} while (0)
+#endif
+
 // s_i(x, y) = s0[i] + bx[i] * (x - x0) + by[i] * (y - y0) (mod 2^32), inside iff all three < 0.
 // A zero-area face (in_tri returns false, auxiliary.h:201-202) and the padding entries of a
 // partially filled 32-face word are stored as the all-zero record, which covers nothing.
@@ -229,16 +252,24 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     FaceIds ids = load_face_ids(p, b, begin + sj < end ? (int)p.face_list[begin + sj] : -1);
     int face_next = begin + CHUNK + sj < end ? (int)p.face_list[begin + CHUNK + sj] : -1;
 
+    DMR_STAMP_RT(p, 0, 0);
     for (uint32_t base = begin; base < end; base += CHUNK) {
+        const uint32_t ph = (base - begin) / CHUNK;  // (phase stamps, ablation build)
+        DMR_STAMP(p, 0, ph, 0);
         if (__syncthreads_and(done)) break;  // also fences LDS reuse
+        DMR_STAMP(p, 0, ph, 1);
         const int n = (int)min((uint32_t)CHUNK, end - base);
         if (!DMR_DBG(p, 64)) stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
         ids = load_face_ids(p, b, face_next);  // in flight while this chunk is composited
         face_next = base + 2 * CHUNK + sj < end ? (int)p.face_list[base + 2 * CHUNK + sj] : -1;
         *reinterpret_cast<uint4*>(&s_pm[tid][0]) = make_uint4(0u, 0u, 0u, 0u);
+        DMR_STAMP(p, 0, ph, 2);
         __syncthreads();
+        DMR_STAMP(p, 0, ph, 3);
         if (!DMR_DBG(p, 16)) rasterize_faces<CHUNK>(s_cov, n, tid, s_pm);  // A
+        DMR_STAMP(p, 0, ph, 4);
         __syncthreads();
+        DMR_STAMP(p, 0, ph, 5);
         uint32_t m[WORDS];
         {
             const uint4 mm = *reinterpret_cast<const uint4*>(&s_pm[ly * TILE + lx][0]);
@@ -284,7 +315,9 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
             n_hits += 1u + n_skipped; n_skipped = 0u;  // the backward lists every covered pair below n_contrib, skipped ones too
             if (T < T_EPS) { done = true; break; }  // blend first, test after (Q9)
         }
+        DMR_STAMP(p, 0, ph, 6);
     }
+    DMR_STAMP_RT(p, 0, 1);
 
     if (begin != end) {  // blended (pixel, face) pairs of the tile: sizes the backward's hit-record buffer
 #pragma unroll
@@ -498,11 +531,14 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     };
     FaceIds ids = load_face_ids(p, b, chunk_face(0));
     int face_next = chunk_face(1);
+    DMR_STAMP_RT(p, 1, 0);
     for (uint32_t ci = 0; ci < nchunks; ci++) {
         const uint32_t hi = total - ci * CHUNK;  // chunk = list positions [lo, hi)
         const uint32_t lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
         const int n = (int)(hi - lo);
+        DMR_STAMP(p, 1, ci, 0);
         __syncthreads();  // previous chunk is done with the LDS records, counters and masks
+        DMR_STAMP(p, 1, ci, 1);
         stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
         if (tid < CHUNK) *reinterpret_cast<int4*>(&s_ids[tid][0]) = make_int4(ids.face, ids.v0, ids.v1, ids.v2);
         ids = load_face_ids(p, b, face_next);  // in flight while this chunk is processed
@@ -511,9 +547,13 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
 #pragma unroll
         for (int w = 0; w < WORDS; w++) s_pm[pl][w] = 0u;
         s_lim[pl] = last_contributor > lo ? min(last_contributor - lo, (uint32_t)CHUNK) : 0u;
+        DMR_STAMP(p, 1, ci, 2);
         __syncthreads();
+        DMR_STAMP(p, 1, ci, 3);
         if (!DMR_DBG(p, 4)) rasterize_faces_counted<CHUNK>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // ---- A
+        DMR_STAMP(p, 1, ci, 4);
         __syncthreads();
+        DMR_STAMP(p, 1, ci, 5);
         if (wave == 0) {  // ---- S: lane l scans counters [l * PER, (l + 1) * PER)
             // A face's records form ONE run padded to a multiple of HIT_GROUP (the hit-parallel kernel takes HIT_GROUP
             // records of one list entry per lane, so its segmented scan runs once per group instead of once per record);
@@ -541,7 +581,9 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
             }
             if (lane == 63) s_chunk_hits = incl;
         }
+        DMR_STAMP(p, 1, ci, 6);
         __syncthreads();
+        DMR_STAMP(p, 1, ci, 7);
         if (tid < CHUNK) {  // the pad records of face `tid` (<= HIT_GROUP - 1): they contribute nothing
             const uint32_t fp = s_fpad[tid], slot0 = hit_cursor - region0 + (fp & 0x0fffffffu), npad = fp >> 28;
             HitRecord pad; pad.pixel = HIT_SKIPPED; pad.T = 0.f; pad.dL_dalpha = 0.f;
@@ -551,6 +593,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
                 if (addr < capacity) hits[addr] = pad;
             }
         }
+        DMR_STAMP(p, 1, ci, 8);
         // ---- B
         uint32_t m[WORDS];
 #pragma unroll
@@ -612,7 +655,9 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
             if (slot < capacity) hits[slot] = hr;  // capacity < total only while a size guess is being refuted
         }
         hit_cursor += s_chunk_hits;  // stable until the next chunk's scan, two barriers away
+        DMR_STAMP(p, 1, ci, 9);
     }
+    DMR_STAMP_RT(p, 1, 1);
     if (tid == 0) p.tile_used[tile] = hit_cursor - region0;  // what the hit-parallel kernel walks (a multiple of HIT_GROUP)
 }
 
@@ -750,6 +795,8 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
 
     __shared__ HitsLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    DMR_STAMP_RT(p, 2, 0);
+    DMR_STAMP(p, 2, 0u, 8);
     for (int i = tid; i < VTAB; i += 256) {
         L.vkey[i] = TAB_EMPTY;
 #pragma unroll
@@ -774,9 +821,11 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     };
     uint4 raw[HIT_GROUP], nxt[HIT_GROUP];
     load_group((uint32_t)tid, nxt);
+    DMR_STAMP(p, 2, 0u, 9);
     for (uint32_t g0 = 0; g0 < ngroups; g0 += 256u) {
         const uint32_t gi = g0 + (uint32_t)tid;
         const bool valid = gi < ngroups;   // lanes past the end: no group, unique keys
+        DMR_STAMP(p, 2, g0 / 256u, 0);
 #pragma unroll
         for (int q = 0; q < HIT_GROUP; q++) raw[q] = nxt[q];
         load_group(gi + 256u, nxt);  // in flight while this round computes (past the end: nothing is loaded)
@@ -801,6 +850,12 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             const V3 xQ = dmr::cross(xT, xE1);
             const float w2 = dmr::dot(xQ, xE2);
             const V3 xE12 = dmr::cross(xE1, xE2), xE2T = dmr::cross(xE2, xT);
+#ifdef DMR_ABLATION
+            if (DMR_DBG(p, 4096)) {  // (phase stamps: the face's gathers have arrived)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                DMR_STAMP(p, 2, g0 / 256u, 1);
+            }
+#endif
 #pragma unroll
             for (int q = 0; q < HIT_GROUP; q++) {
                 if (raw[q].y & HIT_SKIPPED) continue;  // pad, or a pair the forward skipped (denom == 0)
@@ -889,12 +944,14 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         // segmented inclusive scan over the wave (groups of one entry are consecutive lanes): four row-local DPP levels.
         // The scan stops at the 16-lane DPP rows: the table takes partial sums just as well, so an entry that crosses a
         // row boundary simply contributes one more partial.
+        DMR_STAMP(p, 2, g0 / 256u, 2);
         seg_scan_level<DPP_ROW_SHR + 1, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 2, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 4, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 8, 0xF>(k, g);
 
         // segment tails hold the totals: stage them (wave-private LDS), 16 at a time, and add them into the table
+        DMR_STAMP(p, 2, g0 / 256u, 3);
         const int kn = __shfl_down(k, 1, 64);
         const bool tail = valid && ((lane & 15) == 15 || kn != k);
         const uint64_t tmask = __ballot(tail);
@@ -910,15 +967,20 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             }
             if (!DMR_DBG(p, 512)) accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
         }
+        DMR_STAMP(p, 2, g0 / 256u, 4);
     }
     // every row of the table goes out once: 8 lanes per vertex row (7 used)
+    DMR_STAMP(p, 2, 0u, 5);
     __syncthreads();
+    DMR_STAMP(p, 2, 0u, 6);
     if (DMR_DBG(p, 1024)) return;
     for (int s0 = 0; s0 < VTAB; s0 += 32) {
         const int slot = s0 + (tid >> 3), comp = tid & 7;
         const uint32_t rid = L.vkey[slot];
         if (rid != TAB_EMPTY && comp < 7) atomicAdd(&vrow[(int64_t)rid * VROW + comp], (float)L.vval[slot][comp]);
     }
+    DMR_STAMP(p, 2, 0u, 7);
+    DMR_STAMP_RT(p, 2, 1);
 }
 
 #pragma clang fp contract(off)
@@ -1008,3 +1070,24 @@ void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow,
 }
 
 }  // namespace dmr
+
+#ifdef DMR_ABLATION
+// ablation build only (not in include/dmesh_renderer_amd.h): copy out / clear the phase stamps.  which = 0: g_phase, 1: g_phase_rt
+extern "C" __attribute__((visibility("default"))) long long dmr_debug_phase(int which, void* dst, long long bytes, int reset) {
+    const size_t have = which == 0 ? sizeof(dmr::g_phase) : sizeof(dmr::g_phase_rt);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (dst) {
+        const size_t n = std::min((size_t)bytes, have);
+        const hipError_t e = which == 0 ? hipMemcpyFromSymbol(dst, HIP_SYMBOL(dmr::g_phase), n)
+                                        : hipMemcpyFromSymbol(dst, HIP_SYMBOL(dmr::g_phase_rt), n);
+        if (e != hipSuccess) return -1;
+    }
+    if (reset) {
+        void* sym = nullptr;
+        const hipError_t e = which == 0 ? hipGetSymbolAddress(&sym, HIP_SYMBOL(dmr::g_phase))
+                                        : hipGetSymbolAddress(&sym, HIP_SYMBOL(dmr::g_phase_rt));
+        if (e != hipSuccess || hipMemset(sym, 0, have) != hipSuccess) return -1;
+    }
+    return (long long)have;
+}
+#endif
