@@ -22,6 +22,30 @@
 
 namespace dmr {
 
+// "Are all threads of the workgroup done?" with ONE barrier.  __syncthreads_and() compiles to ds_write / s_barrier / ds_and /
+// s_barrier / ds_read / s_barrier on this target: >= 1.5 k cycles at the top of every chunk of a tile's list (phase stamps,
+// profiles/r02/phase_times_c4.txt).  Here a thread that is not done raises word `parity` of a two-word LDS flag before the
+// barrier, everybody reads it after, and thread 0 clears the other word for the next round.  The caller zeroes both words and
+// passes a barrier once before the first call, and has at least one more barrier between two calls (the clear must not
+// overtake the next round's raise).
+struct AllDone {
+    uint32_t* live;   // __shared__ uint32_t[2]
+    uint32_t parity;
+    __device__ __forceinline__ void init(uint32_t* s_live) {
+        live = s_live; parity = 0u;
+        if (threadIdx.x == 0) { live[0] = 0u; live[1] = 0u; }
+        __syncthreads();
+    }
+    __device__ __forceinline__ bool barrier(bool done) {
+        if (!done) live[parity] = 1u;
+        __syncthreads();
+        const bool all = live[parity] == 0u;
+        parity ^= 1u;
+        if (threadIdx.x == 0) live[parity] = 0u;
+        return all;
+    }
+};
+
 constexpr int TILE = 16;            // cuda_*/config.h:5-6 (BLOCK_X = BLOCK_Y = 16)
 constexpr int TILE_PIX = 256;
 constexpr float T_EPS = 0.0001f;    // auxiliary.h:8

@@ -145,8 +145,11 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
     bool done = !inside;
     float min_T = -1.0f, min_T_max_depth = -1.0f;
     int ff = -1;
+    __shared__ uint32_t s_live[2];
+    AllDone all_done;
+    all_done.init(s_live);
     for (uint32_t base = begin; base < end; base += FI_CHUNK) {
-        if (__syncthreads_and(done)) break;
+        if (all_done.barrier(done)) break;
         const int n = (int)min((uint32_t)FI_CHUNK, end - base);
         if (tid < n) {
             const int face = (int)face_list[base + tid];

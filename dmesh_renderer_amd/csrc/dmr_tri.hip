@@ -211,6 +211,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     __shared__ CovRec s_cov[CHUNK];
     __shared__ ShadeRec s_shade[CHUNK];
     __shared__ uint32_t s_pm[TILE_PIX][WORDS];  // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
+    __shared__ uint32_t s_live[2];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
@@ -253,10 +254,12 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     int face_next = begin + CHUNK + sj < end ? (int)p.face_list[begin + CHUNK + sj] : -1;
 
     DMR_STAMP_RT(p, 0, 0);
+    AllDone all_done;
+    all_done.init(s_live);
     for (uint32_t base = begin; base < end; base += CHUNK) {
         const uint32_t ph = (base - begin) / CHUNK;  // (phase stamps, ablation build)
         DMR_STAMP(p, 0, ph, 0);
-        if (__syncthreads_and(done)) break;  // also fences LDS reuse
+        if (all_done.barrier(done)) break;  // also fences LDS reuse
         DMR_STAMP(p, 0, ph, 1);
         const int n = (int)min((uint32_t)CHUNK, end - base);
         if (!DMR_DBG(p, 64)) stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
@@ -797,16 +800,6 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     DMR_STAMP_RT(p, 2, 0);
     DMR_STAMP(p, 2, 0u, 8);
-    for (int i = tid; i < VTAB; i += 256) {
-        L.vkey[i] = TAB_EMPTY;
-#pragma unroll
-        for (int c = 0; c < 7; c++) L.vval[i][c] = 0.0;
-    }
-#if DMR_HITS_PIX_LDS
-    L.pix[tid] = pixrec[2 * (int64_t)tile * TILE_PIX + tid];
-    L.pix[tid + 256] = pixrec[2 * (int64_t)tile * TILE_PIX + 256 + tid];
-#endif
-    __syncthreads();
     const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
 
     // record q of a lane's group: the wave's 64 lanes read one contiguous kilobyte (dmr_kernels.hpp, HIT_BLOCK).
@@ -819,8 +812,23 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
 #pragma unroll
         for (int q = 0; q < HIT_GROUP; q++) r[q] = in ? src[64 * q] : make_uint4(0u, HIT_SKIPPED, 0u, 0u);
     };
+    // the first round's records and the tile's pixels are requested before the table is cleared: the workgroup's set-up
+    // costs one memory latency, not one after the other (phase stamps: 5.1 k cycles of a tile's ~55 k were set-up)
     uint4 raw[HIT_GROUP], nxt[HIT_GROUP];
     load_group((uint32_t)tid, nxt);
+#if DMR_HITS_PIX_LDS
+    const float4 px0 = pixrec[2 * (int64_t)tile * TILE_PIX + tid], px1 = pixrec[2 * (int64_t)tile * TILE_PIX + 256 + tid];
+#endif
+    for (int i = tid; i < VTAB; i += 256) {
+        L.vkey[i] = TAB_EMPTY;
+#pragma unroll
+        for (int c = 0; c < 7; c++) L.vval[i][c] = 0.0;
+    }
+#if DMR_HITS_PIX_LDS
+    L.pix[tid] = px0;
+    L.pix[tid + 256] = px1;
+#endif
+    __syncthreads();
     DMR_STAMP(p, 2, 0u, 9);
     for (uint32_t g0 = 0; g0 < ngroups; g0 += 256u) {
         const uint32_t gi = g0 + (uint32_t)tid;
@@ -974,10 +982,21 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     __syncthreads();
     DMR_STAMP(p, 2, 0u, 6);
     if (DMR_DBG(p, 1024)) return;
-    for (int s0 = 0; s0 < VTAB; s0 += 32) {
-        const int slot = s0 + (tid >> 3), comp = tid & 7;
-        const uint32_t rid = L.vkey[slot];
-        if (rid != TAB_EMPTY && comp < 7) atomicAdd(&vrow[(int64_t)rid * VROW + comp], (float)L.vval[slot][comp]);
+    // (eight slots per lane are read before the first atomic goes out: the LDS latencies overlap instead of adding up)
+    constexpr int FLUSH_BATCH = 8;
+    static_assert(VTAB % (32 * FLUSH_BATCH) == 0, "table size");
+    const int comp = tid & 7;
+    for (int s0 = 0; s0 < VTAB; s0 += 32 * FLUSH_BATCH) {
+        uint32_t rid[FLUSH_BATCH]; float val[FLUSH_BATCH];
+#pragma unroll
+        for (int i = 0; i < FLUSH_BATCH; i++) {
+            const int slot = s0 + 32 * i + (tid >> 3);
+            rid[i] = L.vkey[slot];
+            val[i] = (float)L.vval[slot][comp < 7 ? comp : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < FLUSH_BATCH; i++)
+            if (rid[i] != TAB_EMPTY && comp < 7) atomicAdd(&vrow[(int64_t)rid[i] * VROW + comp], val[i]);
     }
     DMR_STAMP(p, 2, 0u, 7);
     DMR_STAMP_RT(p, 2, 1);
