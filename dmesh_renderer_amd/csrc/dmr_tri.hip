@@ -414,8 +414,10 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
 constexpr uint32_t HIT_SKIPPED = 0x80000000u;
 
 // rasterize_faces of the forward plus: only list positions below the pixel's n_contrib (s_lim = that bound relative
-// to the chunk start) get their bit, and the face's blended-pixel count goes to s_fcnt.
-template <int CHUNK>
+// to the chunk start) get their bit, and the face's blended-pixel count goes to s_fcnt.  LIMIT = false: every pixel's
+// bound lies beyond the chunk (all chunks of a tile but the ones its pixels end in), no look-up per covered pixel -- the
+// dependent LDS read inside the innermost loop made this phase 1.8x the forward's (profiles/r02/phase_times_c4.txt).
+template <int CHUNK, bool LIMIT>
 __device__ __forceinline__ void rasterize_faces_counted(const CovRec* __restrict__ cov, int n, int tid,
                                                         uint32_t (*__restrict__ pm)[CHUNK / 32],
                                                         const uint32_t* __restrict__ s_lim, uint32_t* __restrict__ s_fcnt) {
@@ -435,7 +437,7 @@ __device__ __forceinline__ void rasterize_faces_counted(const CovRec* __restrict
         uint32_t e1 = (uint32_t)c.s0[1] + (uint32_t)c.by[1] * (uint32_t)y + bx1 * (uint32_t)x0;
         uint32_t e2 = (uint32_t)c.s0[2] + (uint32_t)c.by[2] * (uint32_t)y + bx2 * (uint32_t)x0;
         for (int x = x0; x <= x1; x++) {
-            if ((int32_t)(e0 & e1 & e2) < 0 && s_lim[y * TILE + x] > (uint32_t)j) {
+            if ((int32_t)(e0 & e1 & e2) < 0 && (!LIMIT || s_lim[y * TILE + x] > (uint32_t)j)) {
                 atomicOr(&pm[y * TILE + x][word], bit);
                 cnt++;
             }
@@ -461,6 +463,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     __shared__ uint32_t s_lim[TILE_PIX];            // per pixel: n_contrib relative to the chunk start, clamped to [0, 64]
     __shared__ uint32_t s_pm[TILE_PIX][CHUNK / 32]; // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
     __shared__ uint32_t s_max_last, s_chunk_hits;
+    __shared__ uint32_t s_limited;                  // some pixel's bound lies inside the chunk
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {   // every block zeroes its slice of the packed gradient accumulators kernel 2 adds into
@@ -508,7 +511,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     bg_dot += p.bg[0] * dpc0; bg_dot += p.bg[1] * dpc1; bg_dot += p.bg[2] * dpc2;
     const float bd_dot = 0.f + (float)(1.0 * (double)dpd);
 
-    if (tid == 0) s_max_last = 0;
+    if (tid == 0) { s_max_last = 0; s_limited = 0u; }
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_last, last_contributor);
     __syncthreads();
@@ -549,11 +552,18 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         if (tid < CHUNK) s_fcnt[tid] = 0u;
 #pragma unroll
         for (int w = 0; w < WORDS; w++) s_pm[pl][w] = 0u;
-        s_lim[pl] = last_contributor > lo ? min(last_contributor - lo, (uint32_t)CHUNK) : 0u;
+        {
+            const uint32_t lim = last_contributor > lo ? min(last_contributor - lo, (uint32_t)CHUNK) : 0u;
+            s_lim[pl] = lim;
+            if (lim < (uint32_t)n) s_limited = 1u;  // (cleared by the scan wave, one barrier after its last reader)
+        }
         DMR_STAMP(p, 1, ci, 2);
         __syncthreads();
         DMR_STAMP(p, 1, ci, 3);
-        if (!DMR_DBG(p, 4)) rasterize_faces_counted<CHUNK>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // ---- A
+        if (!DMR_DBG(p, 4)) {  // ---- A
+            if (s_limited) rasterize_faces_counted<CHUNK, true>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // uniform
+            else rasterize_faces_counted<CHUNK, false>(s_cov, n, tid, s_pm, s_lim, s_fcnt);
+        }
         DMR_STAMP(p, 1, ci, 4);
         __syncthreads();
         DMR_STAMP(p, 1, ci, 5);
@@ -582,7 +592,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
                 s_fpad[lane * PER + i] = (run + c[i]) | ((cp[i] - c[i]) << 28);  // first pad slot | number of pad slots
                 run += cp[i];
             }
-            if (lane == 63) s_chunk_hits = incl;
+            if (lane == 63) { s_chunk_hits = incl; s_limited = 0u; }
         }
         DMR_STAMP(p, 1, ci, 6);
         __syncthreads();
