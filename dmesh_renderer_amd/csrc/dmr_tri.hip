@@ -710,7 +710,7 @@ constexpr int STAGE_ROW = 28;    // 23 sums, v0, v1, v2, face, view
 #ifndef DMR_HITS_UNROLL
 #define DMR_HITS_UNROLL 1
 #endif
-constexpr int VTAB = DMR_VTAB;   // vertex-row slots per workgroup (power of two)
+constexpr int VTAB = DMR_VTAB;   // vertex-row slots per workgroup
 constexpr int TAB_PROBES = 16;
 constexpr uint32_t TAB_EMPTY = 0xffffffffu;
 
@@ -745,11 +745,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 template <int SLOTS>
 __device__ __forceinline__ int tab_find(uint32_t* __restrict__ key, uint32_t rid) {
-    uint32_t slot = (rid * 2654435761u) & (uint32_t)(SLOTS - 1);
+    constexpr bool POW2 = (SLOTS & (SLOTS - 1)) == 0;
+    const uint32_t h = rid * 2654435761u;
+    uint32_t slot = POW2 ? (h & (uint32_t)(SLOTS - 1)) : __umulhi(h, (uint32_t)SLOTS);
     for (int i = 0; i < TAB_PROBES; i++) {
         const uint32_t prev = atomicCAS(&key[slot], TAB_EMPTY, rid);
         if (prev == TAB_EMPTY || prev == rid) return (int)slot;
-        slot = (slot + 1u) & (uint32_t)(SLOTS - 1);
+        slot = POW2 ? ((slot + 1u) & (uint32_t)(SLOTS - 1)) : (slot + 1u == (uint32_t)SLOTS ? 0u : slot + 1u);
     }
     return -1;
 }
@@ -993,7 +995,7 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     DMR_STAMP(p, 2, 0u, 6);
     if (DMR_DBG(p, 1024)) return;
     // (eight slots per lane are read before the first atomic goes out: the LDS latencies overlap instead of adding up)
-    constexpr int FLUSH_BATCH = 8;
+    constexpr int FLUSH_BATCH = VTAB % 256 == 0 ? 8 : 4;
     static_assert(VTAB % (32 * FLUSH_BATCH) == 0, "table size");
     const int comp = tid & 7;
     for (int s0 = 0; s0 < VTAB; s0 += 32 * FLUSH_BATCH) {
