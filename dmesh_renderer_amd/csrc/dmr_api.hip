@@ -54,8 +54,9 @@ struct ImageState {
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
     int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
+    unsigned long long* mask_offset;  // tri: byte offset of the coverage masks inside the binning buffer (written on the device)
 };
-struct BinningState { uint64_t* keys; uint32_t* face_list; uint32_t capacity; };
+struct BinningState { uint64_t* keys; uint32_t* face_list; uint32_t capacity; unsigned long long mask_offset; };
 
 size_t carve_point(void* b, size_t BP, PointState& s) { Carver c(b); s.vproj = c.take<float4>(BP); return c.off; }
 size_t carve_face(void* b, size_t BF, size_t F, size_t T, bool tet, FaceState& s) {
@@ -75,6 +76,7 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
     Carver c(b);
     s.mats = c.take<float>(64 * B);
     s.seed = c.take<int>(1);
+    s.mask_offset = c.take<unsigned long long>(1);
     // counters, zeroed by k_project_verts at the start of a forward: [tile_count | tile_hits | scan_tmp's buckets]
     s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles);
     s.scan_tmp = c.take<uint32_t>(dmr::scan_tmp_words((int)ntiles));
@@ -94,10 +96,15 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
 }
 // face_list first: the backward re-derives it from the buffer start, whatever capacity the forward
 // gave the buffer (speculative sizing allocates more than R entries)
-size_t carve_binning(void* b, size_t R, BinningState& s) {
+// ... then, tri only, the coverage masks the forward leaves for the backward (dmr_kernels.hpp): their place depends on the
+// capacity, so the kernels take it from the device (ImageState::mask_offset, written by the scatter pass).  mask_tiles = 0:
+// no masks (tet; the backward, which never carves beyond the lists on the host).
+size_t carve_binning(void* b, size_t R, size_t mask_tiles, BinningState& s) {
     Carver c(b);
     s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
     s.capacity = (uint32_t)std::min<size_t>(R, 0xffffffffu);
+    s.mask_offset = c.off;
+    if (mask_tiles && R > 0) c.take<uint4>(dmr::mask_slots(R, mask_tiles) * 256);
     return c.off;
 }
 
@@ -227,12 +234,13 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     };
     auto rest = [&](uint64_t capacity) -> int {
         BinningState tb, bs;
-        void* bb = alloc(ctx, DMR_BUF_BINNING, carve_binning(nullptr, (size_t)capacity, tb));
+        const size_t mask_tiles = tet ? 0 : (size_t)d.ntiles;
+        void* bb = alloc(ctx, DMR_BUF_BINNING, carve_binning(nullptr, (size_t)capacity, mask_tiles, tb));
         if (!bb && capacity > 0) return fail("binning allocation failed");
-        carve_binning(bb, (size_t)capacity, bs);
+        carve_binning(bb, (size_t)capacity, mask_tiles, bs);
         if (capacity > 0) {
             dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
-                                      (uint32_t)capacity, st);
+                                      (uint32_t)capacity, tet ? nullptr : is.mask_offset, bs.mask_offset, st);
             dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, bs.capacity, st);
         }
         render(bs);
@@ -372,7 +380,7 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, bs.capacity, img, out_color,
                                 out_depth, st);
@@ -404,7 +412,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
     carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, false, fs);
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, false, is);
-    carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, bs);
+    carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, 0, bs);
 
     // The forward counted the blended (pixel, face) pairs per tile and in total; the total sizes the record
     // buffer (the backward's one 8-byte host read; speculative sizing as in the forward).
@@ -422,7 +430,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         float* frow = reinterpret_cast<float*>(work + vbytes);
         float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
         dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
         const dmr_scene sc = canonical(s, is.mats);
         // (Splitting the tiles into bands whose hit-parallel kernel runs on a second stream while the next band's
         // per-pixel kernel computes -- atomic unit and SIMDs busy at the same time -- was measured and lost: 0.56 ms
@@ -583,7 +591,7 @@ int64_t dmr_export(const dmr_scene* s, int is_tet, int num_rendered, const char*
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
     carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, is_tet != 0, fs);
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, is_tet != 0, is);
-    carve_binning(const_cast<void*>(binning_buf), (size_t)std::max(0, num_rendered), bs);
+    carve_binning(const_cast<void*>(binning_buf), (size_t)std::max(0, num_rendered), 0, bs);
     const std::string n(name);
     auto plain = [&](const void* src, size_t bytes) -> int64_t {
         if (dst && src && bytes) {

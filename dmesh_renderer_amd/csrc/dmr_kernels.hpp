@@ -52,7 +52,7 @@ void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_of
                        uint32_t capacity, uint32_t* overflow, hipStream_t st);
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
                           const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
-                          hipStream_t st);
+                          unsigned long long* mask_offset_dst, unsigned long long mask_offset, hipStream_t st);
 // capacity: entries the binning buffer holds; it is below R only while a size guess is being refuted (dmr_api.hip):
 // every kernel that walks the tile lists clamps to it, the results are then thrown away and redone
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
@@ -65,7 +65,13 @@ struct TriImageState {
     const uint32_t* hit_offset;     // record regions: exclusive scan of the tiles' record bounds (k_scan_hits, backward)
     uint32_t* tile_used;            // records k_tri_backward_pix wrote into a tile's region (padded runs; <= the bound)
     const uint32_t* tile_order;  // all B * gx * gy tiles, longest list first (k_scan_tiles)
+    // Coverage masks the forward keeps for the backward: one 4 KB slot (256 pixels x 128 face bits) per 128-entry chunk of a
+    // tile's list, slot = list offset / 128 + tile index.  They live in the binning buffer behind the lists, whose capacity
+    // the backward does not know on the host (speculative sizing): the byte offset is kept on the device.
+    const unsigned long long* mask_offset;
 };
+constexpr int MASK_CHUNK = 128;     // list entries per mask slot = the compositing kernels' chunk
+inline size_t mask_slots(size_t list_capacity, size_t ntiles) { return list_capacity / MASK_CHUNK + ntiles + 1; }
 // One blended (pixel, face) pair, written face-major per (tile, chunk, pass) by k_tri_backward_pix and
 // consumed one per lane by k_tri_backward_hits.
 // (A 32-byte record carrying face and vertex ids was tried: kernel 2 did not get faster, kernel 1 got 9 % slower.)

@@ -94,7 +94,16 @@ struct TriParams {
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
     uint32_t* tile_hits; const uint32_t* hit_offset; uint32_t* tile_used; const uint32_t* tile_order;
+    const unsigned long long* mask_offset;  // coverage masks: byte offset behind face_list (TriImageState)
 };
+
+// The chunk's coverage masks, pixel-major: slot (list offset / 128 + tile + chunk) of 256 x 16 bytes.  The forward writes
+// them right after rasterising, the per-pixel backward reads them back instead of staging the coverage records and
+// rasterising the chunk a second time (that was 13 k of its 25 k cycles per chunk, profiles/r02/phase_times_c4.txt).
+__device__ __forceinline__ uint4* chunk_masks(const TriParams& p, int tile, uint32_t begin, uint32_t chunk) {
+    char* base = const_cast<char*>(reinterpret_cast<const char*>(p.face_list)) + *p.mask_offset;
+    return reinterpret_cast<uint4*>(base) + ((size_t)(begin / (uint32_t)MASK_CHUNK) + (size_t)tile + chunk) * TILE_PIX;
+}
 
 // Staging a list entry is a chain of dependent gathers: face_list -> faces (+ opacity, intensity) -> 3 x
 // (projected vertex, position, colour).  While the workgroup waits for it nothing else runs, so the first two
@@ -143,6 +152,28 @@ __device__ __forceinline__ void stage_shade(const TriParams& p, int b, const Fac
     sh.E1[0] = E1.x; sh.E1[1] = E1.y; sh.E1[2] = E1.z;
     sh.E2[0] = E2.x; sh.E2[1] = E2.y; sh.E2[2] = E2.z;
     sh.Q[0] = Q.x; sh.Q[1] = Q.y; sh.Q[2] = Q.z;
+    sh.c0[0] = c0.x; sh.c0[1] = c0.y; sh.c0[2] = c0.z;
+    sh.c1[0] = c1.x; sh.c1[1] = c1.y; sh.c1[2] = c1.z;
+    sh.c2[0] = c2.x; sh.c2[1] = c2.y; sh.c2[2] = c2.z;
+    sh.d0 = d0; sh.d1 = d1; sh.d2 = d2;
+    sh.opacity = f.opacity;
+    sh.intense = f.intense;
+}
+
+// The shading record in two halves, for the per-pixel backward (no coverage records there: two threads per face):
+// geometry (positions -> T, E1, E2, Q) and attributes (colours, depths, opacity, intensity).
+__device__ __forceinline__ void stage_shade_geom(const TriParams& p, const FaceIds& f, V3 ray_o, ShadeRec& sh) {
+    const V3 p0 = load_v3(p.verts, f.v0), p1 = load_v3(p.verts, f.v1), p2 = load_v3(p.verts, f.v2);
+    const V3 T = ray_o - p0, E1 = p1 - p0, E2 = p2 - p0;
+    const V3 Q = cross(T, E1);
+    sh.T[0] = T.x; sh.T[1] = T.y; sh.T[2] = T.z;
+    sh.E1[0] = E1.x; sh.E1[1] = E1.y; sh.E1[2] = E1.z;
+    sh.E2[0] = E2.x; sh.E2[1] = E2.y; sh.E2[2] = E2.z;
+    sh.Q[0] = Q.x; sh.Q[1] = Q.y; sh.Q[2] = Q.z;
+}
+__device__ __forceinline__ void stage_shade_attr(const TriParams& p, int b, const FaceIds& f, ShadeRec& sh) {
+    const V3 c0 = load_v3(p.verts_color, f.v0), c1 = load_v3(p.verts_color, f.v1), c2 = load_v3(p.verts_color, f.v2);
+    const float d0 = p.vproj[(int64_t)b * p.P + f.v0].w, d1 = p.vproj[(int64_t)b * p.P + f.v1].w, d2 = p.vproj[(int64_t)b * p.P + f.v2].w;
     sh.c0[0] = c0.x; sh.c0[1] = c0.y; sh.c0[2] = c0.z;
     sh.c1[0] = c1.x; sh.c1[1] = c1.y; sh.c1[2] = c1.z;
     sh.c2[0] = c2.x; sh.c2[1] = c2.y; sh.c2[2] = c2.z;
@@ -254,6 +285,8 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     int face_next = begin + CHUNK + sj < end ? (int)p.face_list[begin + CHUNK + sj] : -1;
 
     DMR_STAMP_RT(p, 0, 0);
+    static_assert(CHUNK == MASK_CHUNK, "one mask slot per chunk");
+    uint4* __restrict__ masks = chunk_masks(p, tile, begin, 0u);
     AllDone all_done;
     all_done.init(s_live);
     for (uint32_t base = begin; base < end; base += CHUNK) {
@@ -277,6 +310,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         {
             const uint4 mm = *reinterpret_cast<const uint4*>(&s_pm[ly * TILE + lx][0]);
             m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+            masks[(size_t)ph * TILE_PIX + (ly * TILE + lx)] = mm;  // kept for the backward (every pixel: it applies its own bound)
         }
 #pragma unroll
         for (int w = 0; w < WORDS; w++) if (done || DMR_DBG(p, 8)) m[w] = 0;
@@ -413,40 +447,6 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
 // tests/tools/fuzz_campaign.py: a sliver face whose denom is 0 at some pixels only).
 constexpr uint32_t HIT_SKIPPED = 0x80000000u;
 
-// rasterize_faces of the forward plus: only list positions below the pixel's n_contrib (s_lim = that bound relative
-// to the chunk start) get their bit, and the face's blended-pixel count goes to s_fcnt.  LIMIT = false: every pixel's
-// bound lies beyond the chunk (all chunks of a tile but the ones its pixels end in), no look-up per covered pixel -- the
-// dependent LDS read inside the innermost loop made this phase 1.8x the forward's (profiles/r02/phase_times_c4.txt).
-template <int CHUNK, bool LIMIT>
-__device__ __forceinline__ void rasterize_faces_counted(const CovRec* __restrict__ cov, int n, int tid,
-                                                        uint32_t (*__restrict__ pm)[CHUNK / 32],
-                                                        const uint32_t* __restrict__ s_lim, uint32_t* __restrict__ s_fcnt) {
-    constexpr int TPF = 256 / CHUNK;  // threads per face
-    const int j = tid / TPF, sub = tid % TPF;
-    if (j >= n) return;
-    const CovRec& c = cov[j];
-    const int fl = c.flags;
-    if (!(fl & COV_VALID)) return;
-    const int x0 = fl & 15, x1 = (fl >> 4) & 15, y0 = (fl >> 8) & 15, y1 = (fl >> 12) & 15;
-    const uint32_t bit = 1u << (j & 31);
-    const int word = j >> 5;
-    const uint32_t bx0 = (uint32_t)c.bx[0], bx1 = (uint32_t)c.bx[1], bx2 = (uint32_t)c.bx[2];
-    uint32_t cnt = 0;
-    for (int y = y0 + sub; y <= y1; y += TPF) {
-        uint32_t e0 = (uint32_t)c.s0[0] + (uint32_t)c.by[0] * (uint32_t)y + bx0 * (uint32_t)x0;
-        uint32_t e1 = (uint32_t)c.s0[1] + (uint32_t)c.by[1] * (uint32_t)y + bx1 * (uint32_t)x0;
-        uint32_t e2 = (uint32_t)c.s0[2] + (uint32_t)c.by[2] * (uint32_t)y + bx2 * (uint32_t)x0;
-        for (int x = x0; x <= x1; x++) {
-            if ((int32_t)(e0 & e1 & e2) < 0 && (!LIMIT || s_lim[y * TILE + x] > (uint32_t)j)) {
-                atomicOr(&pm[y * TILE + x][word], bit);
-                cnt++;
-            }
-            e0 += bx0; e1 += bx1; e2 += bx2;
-        }
-    }
-    if (cnt) atomicAdd(&s_fcnt[j], cnt);
-}
-
 __global__ void __launch_bounds__(256, DMR_PIX_WAVES)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity,
@@ -454,16 +454,13 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     constexpr int CHUNK = BWD_CHUNK;
     constexpr int WORDS = CHUNK / 32;
     static_assert(CHUNK == 128, "one wave scans the face counters, two per lane; 256 threads stage 128 + 128 records");
-    __shared__ CovRec s_cov[CHUNK];
+    static_assert(CHUNK == MASK_CHUNK, "the forward's chunks: one mask slot each");
     __shared__ ShadeRec s_shade[CHUNK];
-    __shared__ uint32_t s_fcnt[CHUNK];              // blended pixels per face of the chunk
+    __shared__ uint32_t s_fcnt[CHUNK];              // blended pixels per face of the chunk (zero between chunks)
     __shared__ uint32_t s_fcur[CHUNK];              // exclusive scan of the padded s_fcnt, then the claim cursor per face
     __shared__ uint32_t s_fpad[CHUNK];              // first pad slot of the face's run | number of pad slots << 28
     __shared__ int s_ids[CHUNK][HIT_GROUP];         // face id and its three vertex ids: word q rides in record q of every group
-    __shared__ uint32_t s_lim[TILE_PIX];            // per pixel: n_contrib relative to the chunk start, clamped to [0, 64]
-    __shared__ uint32_t s_pm[TILE_PIX][CHUNK / 32]; // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
     __shared__ uint32_t s_max_last, s_chunk_hits;
-    __shared__ uint32_t s_limited;                  // some pixel's bound lies inside the chunk
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {   // every block zeroes its slice of the packed gradient accumulators kernel 2 adds into
@@ -511,7 +508,8 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     bg_dot += p.bg[0] * dpc0; bg_dot += p.bg[1] * dpc1; bg_dot += p.bg[2] * dpc2;
     const float bd_dot = 0.f + (float)(1.0 * (double)dpd);
 
-    if (tid == 0) { s_max_last = 0; s_limited = 0u; }
+    if (tid == 0) s_max_last = 0;
+    if (tid < CHUNK) s_fcnt[tid] = 0u;
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_last, last_contributor);
     __syncthreads();
@@ -527,45 +525,59 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     const uint32_t region0 = p.hit_offset[tile];
 
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
-    // staging pipeline (threads < CHUNK), chunks walked from the back: chunk ci = list positions [lo, hi) with
-    // hi = total - ci * CHUNK; thread t stages position lo + t
-    const int sj = tid & (CHUNK - 1);  // the chunk face this thread stages (see stage_chunk)
+    // Chunks are the forward's (list positions [c * CHUNK, (c + 1) * CHUNK), cut at `total`), walked from the back;
+    // thread t stages position lo + (t mod CHUNK): threads < CHUNK the geometry half of its record, the others the attributes.
+    const int sj = tid & (CHUNK - 1);
     auto chunk_face = [&](uint32_t ci) -> int {
         if (ci >= nchunks) return -1;
-        const uint32_t hi = total - ci * CHUNK, lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
+        const uint32_t lo = (nchunks - 1u - ci) * CHUNK, hi = min(total, lo + (uint32_t)CHUNK);
         return lo + (uint32_t)sj < hi ? (int)p.face_list[begin + lo + sj] : -1;
     };
+    const uint4* __restrict__ masks = chunk_masks(p, tile, begin, 0u);
     FaceIds ids = load_face_ids(p, b, chunk_face(0));
     int face_next = chunk_face(1);
     DMR_STAMP_RT(p, 1, 0);
     for (uint32_t ci = 0; ci < nchunks; ci++) {
-        const uint32_t hi = total - ci * CHUNK;  // chunk = list positions [lo, hi)
-        const uint32_t lo = hi > (uint32_t)CHUNK ? hi - CHUNK : 0u;
+        const uint32_t fc = nchunks - 1u - ci;  // the forward's chunk index
+        const uint32_t lo = fc * CHUNK, hi = min(total, lo + (uint32_t)CHUNK);  // chunk = list positions [lo, hi)
         const int n = (int)(hi - lo);
         DMR_STAMP(p, 1, ci, 0);
-        __syncthreads();  // previous chunk is done with the LDS records, counters and masks
+        // ---- A: this pixel's coverage bits of the chunk, as the forward's rasterisation left them (requested before the
+        // barrier, in flight across it), restricted to list positions below the pixel's n_contrib (backward.cu:192-194)
+        uint4 mm = masks[(size_t)fc * TILE_PIX + pl];
+        __syncthreads();  // previous chunk is done with the LDS records and cursors
         DMR_STAMP(p, 1, ci, 1);
-        stage_chunk<CHUNK>(p, b, ids, n, tid, tx * TILE, ty * TILE, view_o, s_cov, s_shade);
-        if (tid < CHUNK) *reinterpret_cast<int4*>(&s_ids[tid][0]) = make_int4(ids.face, ids.v0, ids.v1, ids.v2);
+        if (tid < CHUNK) {
+            if (sj < n) stage_shade_geom(p, ids, view_o, s_shade[sj]);
+            *reinterpret_cast<int4*>(&s_ids[tid][0]) = make_int4(ids.face, ids.v0, ids.v1, ids.v2);
+        } else if (sj < n) {
+            stage_shade_attr(p, b, ids, s_shade[sj]);
+        }
         ids = load_face_ids(p, b, face_next);  // in flight while this chunk is processed
         face_next = chunk_face(ci + 2);
-        if (tid < CHUNK) s_fcnt[tid] = 0u;
-#pragma unroll
-        for (int w = 0; w < WORDS; w++) s_pm[pl][w] = 0u;
+        uint32_t m[WORDS] = {mm.x, mm.y, mm.z, mm.w};
         {
-            const uint32_t lim = last_contributor > lo ? min(last_contributor - lo, (uint32_t)CHUNK) : 0u;
-            s_lim[pl] = lim;
-            if (lim < (uint32_t)n) s_limited = 1u;  // (cleared by the scan wave, one barrier after its last reader)
+            const int lim = last_contributor > lo ? (int)min(last_contributor - lo, (uint32_t)CHUNK) : 0;
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                const int keep = lim - 32 * w;  // bits of word w below the bound
+                m[w] = (keep >= 32 && !DMR_DBG(p, 4)) ? m[w] : (keep <= 0 || DMR_DBG(p, 4) ? 0u : (m[w] & ((1u << keep) - 1u)));
+            }
+            // ... and every face's number of such pixels (the counters are zero between chunks: the scan wave clears them)
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) {
+                uint32_t t = m[w];
+                while (t) {
+                    const int bit = __ffs(t) - 1;
+                    t &= t - 1u;
+                    atomicAdd(&s_fcnt[32 * w + bit], 1u);
+                }
+            }
         }
         DMR_STAMP(p, 1, ci, 2);
         __syncthreads();
         DMR_STAMP(p, 1, ci, 3);
-        if (!DMR_DBG(p, 4)) {  // ---- A
-            if (s_limited) rasterize_faces_counted<CHUNK, true>(s_cov, n, tid, s_pm, s_lim, s_fcnt);  // uniform
-            else rasterize_faces_counted<CHUNK, false>(s_cov, n, tid, s_pm, s_lim, s_fcnt);
-        }
         DMR_STAMP(p, 1, ci, 4);
-        __syncthreads();
         DMR_STAMP(p, 1, ci, 5);
         if (wave == 0) {  // ---- S: lane l scans counters [l * PER, (l + 1) * PER)
             // A face's records form ONE run padded to a multiple of HIT_GROUP (the hit-parallel kernel takes HIT_GROUP
@@ -576,6 +588,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
 #pragma unroll
             for (int i = 0; i < PER; i++) {
                 c[i] = s_fcnt[lane * PER + i];
+                s_fcnt[lane * PER + i] = 0u;  // for the next chunk's count (two barriers away)
                 cp[i] = (c[i] + (uint32_t)(HIT_GROUP - 1)) & ~(uint32_t)(HIT_GROUP - 1);
                 sum += cp[i];
             }
@@ -592,7 +605,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
                 s_fpad[lane * PER + i] = (run + c[i]) | ((cp[i] - c[i]) << 28);  // first pad slot | number of pad slots
                 run += cp[i];
             }
-            if (lane == 63) { s_chunk_hits = incl; s_limited = 0u; }
+            if (lane == 63) s_chunk_hits = incl;
         }
         DMR_STAMP(p, 1, ci, 6);
         __syncthreads();
@@ -608,9 +621,6 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         }
         DMR_STAMP(p, 1, ci, 8);
         // ---- B
-        uint32_t m[WORDS];
-#pragma unroll
-        for (int w = 0; w < WORDS; w++) m[w] = s_pm[pl][w];
         while (true) {
             int w = -1; uint32_t mw = 0;
 #pragma unroll
@@ -1056,6 +1066,7 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
     p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset; p.tile_used = img.tile_used; p.tile_order = img.tile_order;
+    p.mask_offset = img.mask_offset;
     p.list_capacity = 0xffffffffu;
     return p;
 }
