@@ -232,7 +232,7 @@ __device__ __forceinline__ void rasterize_faces(const CovRec* __restrict__ cov, 
 #define DMR_FWD_WAVES 4
 #endif
 #ifndef DMR_PIX_WAVES
-#define DMR_PIX_WAVES 5
+#define DMR_PIX_WAVES 6
 #endif
 template <int CHUNK>
 __global__ void __launch_bounds__(256, DMR_FWD_WAVES)
@@ -422,23 +422,24 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
 // ---------------------------------------------------------------------------
 // backward, kernel 1 of 2: k_tri_backward_pix -- the per-pixel sequential part.
 //
-// Per chunk of 64 list entries (walked from the back of the tile list):
-//   A. coverage as in the forward, restricted per pixel to list positions below its n_contrib
-//      (backward.cu:192-194): every pixel gets a 64-bit mask of the chunk faces it blended, and every face the
-//      number of such pixels (counted by the rasterising threads, one ds_add_u32 per thread).
-//   S. one wave scans the 64 counts: face-major slot ranges inside the tile's record region (the region itself
+// Per chunk of 128 list entries (the forward's chunks, walked from the back of the tile list):
+//   A. coverage: the pixel's 128-bit mask of the chunk comes from the forward (chunk_masks: what its rasterisation found),
+//      cut at the pixel's n_contrib (backward.cu:192-194); every pixel adds one to the counter of each face it blended
+//      (ds_add_u32).  Meanwhile the chunk's shading records are staged, two threads per face.  (Up to round 2 this kernel
+//      staged the coverage records and rasterised every chunk a second time: 13 k of its 25 k cycles per chunk.)
+//   S. one wave scans the 128 counts: face-major slot ranges inside the tile's record region (the region itself
 //      starts at the scan of the per-tile hit counts the forward accumulated).
 //   B. every pixel walks its mask from the back: recover T (Q10), the running accum_rec terms and dL/dalpha
 //      (backward.cu:244-308), claim a slot of the face with a returning ds_add_u32 and write the 16-byte
 //      HitRecord straight to HBM.  Within a face the records are in claim order, which kernel 2 does not care about.
-// Everything that needs 23 accumulators per face happens in kernel 2, so this kernel keeps the forward's
-// register/LDS footprint.  History (all measured at C4, see profiles/r01): fused versions -- 23 ds_add_f32 per
-// hit: 59 % of wave cycles stalled on LDS issue (1.26 ms); one thread per (face, quadrant) accumulating in
-// registers: ~15 % lane utilisation (1.25 ms); hit-parallel phase with a segmented scan inside this kernel: 168
-// VGPRs + 50 KB LDS -> 3 waves/SIMD, 0.56 ms.  Two-kernel versions -- hits parked in an LDS pool per pass of at
+// Everything that needs 23 accumulators per face happens in kernel 2, so this kernel keeps a small
+// register/LDS footprint (79 VGPRs, 18 KB: six workgroups per CU).  History (all measured at C4, see profiles/r01): fused
+// versions -- 23 ds_add_f32 per hit: 59 % of wave cycles stalled on LDS issue (1.26 ms); one thread per (face, quadrant)
+// accumulating in registers: ~15 % lane utilisation (1.25 ms); hit-parallel phase with a segmented scan inside this kernel:
+// 168 VGPRs + 50 KB LDS -> 3 waves/SIMD, 0.56 ms.  Two-kernel versions -- hits parked in an LDS pool per pass of at
 // most 8 per pixel, transposed face-major by 64 wave ballots + block scan (0.274 ms), by per-pass counting with
 // integer LDS atomics (0.146 ms); counting during rasterisation removed the passes, the pool and 4 of the ~9
-// barriers per chunk.
+// barriers per chunk (0.100 ms); the forward's masks removed the rasterisation (0.081 ms).
 // ---------------------------------------------------------------------------
 // Bit 31 of HitRecord.pixel (pixel indices fit 31 bits, check_scene): a covered pair the forward skipped (denom == 0,
 // forward.cu:429-430).  Its record stays a member of its list entry's run of records -- same key in the hit-parallel
@@ -610,12 +611,12 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         DMR_STAMP(p, 1, ci, 6);
         __syncthreads();
         DMR_STAMP(p, 1, ci, 7);
-        if (tid < CHUNK) {  // the pad records of face `tid` (<= HIT_GROUP - 1): they contribute nothing
-            const uint32_t fp = s_fpad[tid], slot0 = hit_cursor - region0 + (fp & 0x0fffffffu), npad = fp >> 28;
+        {   // the pad records of face `sj` (<= HIT_GROUP - 1, they contribute nothing): two threads per face, alternating
+            const uint32_t fp = s_fpad[sj], slot0 = hit_cursor - region0 + (fp & 0x0fffffffu), npad = fp >> 28;
             HitRecord pad; pad.pixel = HIT_SKIPPED; pad.T = 0.f; pad.dL_dalpha = 0.f;
-            for (uint32_t q = 0; q < npad; q++) {
+            for (uint32_t q = (uint32_t)(tid >> 7); q < npad; q += 2u) {
                 const uint32_t addr = region0 + hit_slot_address(slot0 + q);
-                pad.id = (uint32_t)s_ids[tid][(slot0 + q) & (uint32_t)(HIT_GROUP - 1)];
+                pad.id = (uint32_t)s_ids[sj][(slot0 + q) & (uint32_t)(HIT_GROUP - 1)];
                 if (addr < capacity) hits[addr] = pad;
             }
         }

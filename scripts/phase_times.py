@@ -29,7 +29,7 @@ KERNELS = ("k_tri_forward", "k_tri_backward_pix", "k_tri_backward_hits")
 PHASES = {
     0: [("barrier (top; waits for the slowest wave of the previous chunk)", 0, 1), ("stage records", 1, 2), ("barrier", 2, 3),
         ("rasterise (face-parallel)", 3, 4), ("barrier", 4, 5), ("walk + shade own bits", 5, 6)],
-    1: [("barrier (top)", 0, 1), ("stage records", 1, 2), ("barrier", 2, 3), ("rasterise + count", 3, 4), ("barrier", 4, 5),
+    1: [("barrier (top)", 0, 1), ("stage shading records, cut the forward's masks, count per face", 1, 2), ("barrier", 2, 3),
         ("scan counters (wave 0)", 5, 6), ("barrier", 6, 7), ("pad records", 7, 8), ("walk own bits, write records", 8, 9)],
     2: [("records + face gathers arrive", 0, 1), ("23 components of <= 4 pairs", 1, 2), ("segmented DPP scan", 2, 3),
         ("stage tails, table adds, face-row atomics", 3, 4)],
