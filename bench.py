@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--opacity", default=None, help="lo,hi: face opacities U(lo, hi) instead of the config's (0.5,0.95 = the early-out scene)")
     ap.add_argument("--no-early-out", action="store_true", help="skip the second, early-termination record (tri, N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true", help="time default (waiting) calls instead of asynchronous ones")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing table to stderr")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous only (gloo, no GPU): prints n_gpus")
     ap.add_argument("--emulate-rank", default=None, metavar="R/N",
@@ -174,6 +175,7 @@ def main():
     # one untimed full forward: scene statistics, and the work-balanced tile-row band of this rank
     out = forward()
     bufs = out[-4:]
+    R_returned = None if tet else int(out[0])  # num_rendered as a default (waiting) call returns it
     ranges = _C.export("ranges", args, tet, 0 if tet else out[0], bufs, H, W, th.int32).cpu().numpy().reshape(-1, 2).astype(np.int64)
     lens = ranges[:, 1] - ranges[:, 0]
     R_full = int(lens.sum())
@@ -239,14 +241,30 @@ def main():
         dd = th.tensor([dom], dtype=th.int64, device=dev)
         dist.broadcast(dd, 0)
         dom = int(dd.item())
-    _C.profile_enable(1 << dom)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        o, g = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    _C.profile_enable(0)
+    # The timed steps are ASYNCHRONOUS calls (C ABI DMR_FLAG_ASYNC): buffers sized from the warm-up steps'
+    # estimates, no device->host size read-back inside a step (the reference waits for 4 bytes in every forward,
+    # rasterizer_impl.cu:287-292).  The device raises a sticky flag if a step outgrew its buffers; it is read after the timed
+    # region, and the measurement is then repeated with default (waiting) calls.  --sync times default calls from the start.
+    def timed(asynchronous):
+        _C.overflowed()  # clear
+        _C.set_async(asynchronous)
+        _C.profile_enable(1 << dom)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            o, g = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        _C.profile_enable(0)
+        _C.set_async(False)
+        return o, g, dt, bool(_C.overflowed())
+
+    host_sync = "per call (default)" if a.sync else "none in the timed steps (asynchronous calls, overflow flag read afterwards)"
+    o, g, dt, overflowed = timed(not a.sync)
+    if overflowed:
+        collect()
+        host_sync = "per call (default): the asynchronous steps overflowed their buffers and were discarded"
+        o, g, dt, _ = timed(False)
     ms, cnt = collect()
     if world > 1:
         tt = th.tensor([dt], dtype=th.float64, device=dev)
@@ -378,7 +396,7 @@ def main():
         if tet:
             parity["active_equal"] = bool(np.array_equal(o[3].cpu().numpy(), oactive))
         else:
-            parity["num_rendered_equal"] = bool(o[0] == ost.num_rendered)
+            parity["num_rendered_equal"] = bool(R_returned == ost.num_rendered)
 
     if rank == 0:
         line = {
@@ -389,6 +407,7 @@ def main():
             "config": dict({"workload": f"{a.config}: {cfg.name}, {'Kuhn lattice' if tet else 'layered sheets'} seed 0, B={B}"
                                         + (f", opacity U({a.opacity})" if a.opacity else ""),
                             "renderer": cfg.kind, "triangles": F, "verts": P, "image": [H, W], "num_rendered": int(R_full),
+                            "host_sync": host_sync,
                             "parallelism": (f"EMULATED rank {emu[0]} of {emu[1]}: its tile-row band {rows}, no collective" if emu else
                                             "single GPU" if world == 1 else f"tile-row bands x{world} + 1 RCCL all-reduce")}, **stats),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stages, "early_out": early,
