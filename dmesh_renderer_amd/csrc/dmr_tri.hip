@@ -377,6 +377,9 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 // backward: shared helpers
 // ---------------------------------------------------------------------------
 constexpr int NACC = 23;  // 9 dverts, 9 dvcolor, 3 dvdepth, dopacity, dintense
+// What a lane of k_tri_backward_hits sums per list entry and the segmented scan carries: the vertex-position gradient as
+// the 7 ray moments (B, A2, S3) it is linear in (see there), then 9 dvcolor, 3 dvdepth, dopacity, dintense.
+constexpr int NSCAN = 21;
 
 // DPP lane move (VALU, no LDS traffic): a lane whose source is outside its 16-lane row keeps `old`.
 template <int CTRL, int ROW_MASK>
@@ -387,7 +390,7 @@ __device__ __forceinline__ int dpp_i(int old, int src) {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 constexpr int DPP_ROW_SHR = 0x110;      // + n, n = 1..15
 
-// One level of the segmented inclusive scan over the 23 components: g += m * g[source lane], m = 1.0 where the
+// One level of the segmented inclusive scan over the 21 sums: g += m * g[source lane], m = 1.0 where the
 // source lane carries the same list entry, else 0.0.  One v_fmac_f32_dpp per value (scripts/micro/valu_rates.hip:
 // 4.8 SIMD cycles, against 9.1 for the v_cndmask_b32_dpp + v_add_f32 pair this replaces; v_add_f32_dpp under an
 // EXEC mask cannot be used because DPP does not read EXEC-disabled source lanes).  Lanes without a valid source
@@ -399,18 +402,17 @@ constexpr int DPP_ROW_SHR = 0x110;      // + n, n = 1..15
                  DMR_SEG1(0, DPP) DMR_SEG1(1, DPP) DMR_SEG1(2, DPP) DMR_SEG1(3, DPP) DMR_SEG1(4, DPP) DMR_SEG1(5, DPP)  \
                  DMR_SEG1(6, DPP) DMR_SEG1(7, DPP) DMR_SEG1(8, DPP) DMR_SEG1(9, DPP) DMR_SEG1(10, DPP) DMR_SEG1(11, DPP) \
                  DMR_SEG1(12, DPP) DMR_SEG1(13, DPP) DMR_SEG1(14, DPP) DMR_SEG1(15, DPP) DMR_SEG1(16, DPP)          \
-                 DMR_SEG1(17, DPP) DMR_SEG1(18, DPP) DMR_SEG1(19, DPP) DMR_SEG1(20, DPP) DMR_SEG1(21, DPP)          \
-                 DMR_SEG1(22, DPP)                                                                             \
+                 DMR_SEG1(17, DPP) DMR_SEG1(18, DPP) DMR_SEG1(19, DPP) DMR_SEG1(20, DPP)                           \
                  : [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]),              \
                    [g5] "+v"(g[5]), [g6] "+v"(g[6]), [g7] "+v"(g[7]), [g8] "+v"(g[8]), [g9] "+v"(g[9]),             \
                    [g10] "+v"(g[10]), [g11] "+v"(g[11]), [g12] "+v"(g[12]), [g13] "+v"(g[13]), [g14] "+v"(g[14]),   \
                    [g15] "+v"(g[15]), [g16] "+v"(g[16]), [g17] "+v"(g[17]), [g18] "+v"(g[18]), [g19] "+v"(g[19]),   \
-                   [g20] "+v"(g[20]), [g21] "+v"(g[21]), [g22] "+v"(g[22])                                      \
+                   [g20] "+v"(g[20])                                                                            \
                  : [m] "v"(m))
 
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void seg_scan_level(int k, float (&g)[NACC]) {
-    static_assert(NACC == 23, "the asm lists 23 registers");
+__device__ __forceinline__ void seg_scan_level(int k, float (&g)[NSCAN]) {
+    static_assert(NSCAN == 21, "the asm lists 21 registers");
     const int ko = dpp_i<CTRL, ROW_MASK>((int)0x80000000, k);
     const float m = (ko == k) ? 1.0f : 0.0f;  // keys are list entries (< 2^31) or negative per-lane ids: never 0x80000000
     if (CTRL == DPP_ROW_SHR + 1) DMR_SEG_LEVEL("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
@@ -686,14 +688,16 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
 }
 
 // ---------------------------------------------------------------------------
-// backward, kernel 2 of 2: k_tri_backward_hits -- one lane per blended (pixel, face) pair.
+// backward, kernel 2 of 2: k_tri_backward_hits -- one lane per group of four (pixel, face) pairs of one list entry.
 //
-// Flat over the hit records (face-major inside every (tile, chunk, pass) group), no workgroup barriers.
-// Each lane gathers its face and pixel data, recomputes the pixel-dependent geometry and the 23 gradient
-// components of backward.cu:313-382; a segmented DPP wave scan keyed by the list entry leaves each
-// entry's total in the last lane of its segment; segment totals are staged in wave-private LDS and flushed
-// with PACKED global atomics: 3 vertex rows + 1 face row per segment (4 memory-side requests) instead of
-// the reference's 23 global atomics per (pixel, face) (backward.cu:389-418).
+// One workgroup per tile, no barriers in its loop.  A lane gathers its face once, recomputes each pair's (u, v) and
+// clamp region exactly as the forward did, and adds the pair to 21 sums: the colour / depth / opacity / intensity
+// gradients of backward.cu:313-382 and, for the vertex positions, the seven RAY MOMENTS ray_tri_intersection_grad is
+// linear in (see the loop).  A segmented DPP scan keyed by the face leaves each entry's totals in the last lane of its
+// segment; that lane turns the moments into the three position gradients (six cross products per list entry instead of
+// ~150 instructions per pair), adds its three vertex rows into the tile's LDS table and sends the face row out.  The
+// table leaves as packed global atomics once per tile: against the reference's 23 global atomics per (pixel, face)
+// (backward.cu:389-418).
 // ---------------------------------------------------------------------------
 // From here to k_tri_backward_hits' end the compiler may contract a*b+c to FMA: gradients are checked to 1e-4
 // and the reference's own sums are unordered float atomics.  F3 is this block's vector type (the V3 helpers of
@@ -713,8 +717,6 @@ __device__ __forceinline__ F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y,
 __device__ __forceinline__ F3 load3(const float* __restrict__ a, int id) { return {a[3 * id], a[3 * id + 1], a[3 * id + 2]}; }
 }  // namespace fm
 
-constexpr int STAGE_SEGS = 16;   // segment totals handled per round and wave: 16 x (3 vertex rows + 1 face row) = 64 refs
-constexpr int STAGE_ROW = 28;    // 23 sums, v0, v1, v2, face, view
 #ifndef DMR_VTAB
 #define DMR_VTAB 512
 #endif
@@ -736,6 +738,9 @@ constexpr uint32_t TAB_EMPTY = 0xffffffffu;
 // per CU, ds_add_f64 ten times that (scripts/micro/lds_atomics.hip).  A full table or a long probe sequence falls
 // back to the direct atomics for that row.  Face rows (opacity, intensity) are unique per (tile, face): a table cannot
 // merge anything but the partial sums of one entry, so they go out directly, one 8-byte request per segment tail.
+// What the atomics cost at C4 (timing builds without them, round 2): the table's flush 23 us (0.53 M requests), the
+// face rows 11 us (0.9 M) of the kernel's 106; staging the tails through LDS so that every lane takes one row (the
+// earlier layout) cost 5 us more than letting the tail lanes add their three rows from registers.
 #ifndef DMR_HITS_PIX_LDS
 #define DMR_HITS_PIX_LDS 1
 #endif
@@ -743,65 +748,33 @@ struct HitsLds {
 #if DMR_HITS_PIX_LDS
     float4 pix[2 * TILE_PIX];   // the tile's pixels: (ray direction, dL/ddepth), (dL/dcolor, -)
 #endif
-    float stage[4][STAGE_SEGS][STAGE_ROW];
     uint32_t vkey[VTAB];
     double vval[VTAB][7];   // dx dy dz dr dg db ddepth of row (view, vertex)
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
+// Rows 2k and 2k + 1 share a 64-byte line of `vrow`; they hash to the two slots of one PAIR of slots (the probe sequence
+// moves pair by pair and keeps the row's parity), so the flush -- consecutive slots in consecutive lane groups of one
+// instruction -- sends both out in one memory-side request whenever a tile holds both (neighbouring vertex ids are
+// neighbouring vertices in most meshes; nothing is lost when they are not): 106.6 -> 102.6 us at C4.
 template <int SLOTS>
 __device__ __forceinline__ int tab_find(uint32_t* __restrict__ key, uint32_t rid) {
-    constexpr bool POW2 = (SLOTS & (SLOTS - 1)) == 0;
-    const uint32_t h = rid * 2654435761u;
-    uint32_t slot = POW2 ? (h & (uint32_t)(SLOTS - 1)) : __umulhi(h, (uint32_t)SLOTS);
+    constexpr int PAIRS = SLOTS / 2;
+    constexpr bool POW2 = (PAIRS & (PAIRS - 1)) == 0;
+    static_assert(SLOTS % 2 == 0, "pairs of slots");
+    const uint32_t h = (rid >> 1) * 2654435761u;
+    uint32_t pair = POW2 ? ((h >> 8) & (uint32_t)(PAIRS - 1)) : __umulhi(h, (uint32_t)PAIRS);
     for (int i = 0; i < TAB_PROBES; i++) {
+        const uint32_t slot = 2u * pair + (rid & 1u);
         const uint32_t prev = atomicCAS(&key[slot], TAB_EMPTY, rid);
         if (prev == TAB_EMPTY || prev == rid) return (int)slot;
-        slot = POW2 ? ((slot + 1u) & (uint32_t)(SLOTS - 1)) : (slot + 1u == (uint32_t)SLOTS ? 0u : slot + 1u);
+        pair = POW2 ? ((pair + 1u) & (uint32_t)(PAIRS - 1)) : (pair + 1u == (uint32_t)PAIRS ? 0u : pair + 1u);
     }
     return -1;
 }
 
-// The n <= 16 segment totals a wave has just staged: lane (seg, w) adds row w of segment seg (w < 3: a vertex
-// row into the table, w == 3: the face row straight to HBM).
-__device__ __forceinline__ void accumulate_staged(const TriParams& p, HitsLds& L, int wave, int lane, int n,
-                                                  float* __restrict__ vrow, float* __restrict__ frow) {
-    wave_lds_sync();  // the staged rows are visible to the whole wave
-    const int sg = lane >> 2, w = lane & 3;
-    if (sg < n) {
-        const float* row = L.stage[wave][sg];
-        const int sb = __float_as_int(row[27]);
-        if (w < 3) {
-            const uint32_t rid = (uint32_t)sb * (uint32_t)p.P + (uint32_t)__float_as_int(row[23 + w]);
-            // (ablation build, DMR_ABLATE bit 2048, tests only: odd rows are refused a slot, which exercises the direct-atomic fallback)
-            const int slot = (DMR_DBG(p, 2048) && (rid & 1u)) ? -1 : tab_find<VTAB>(L.vkey, rid);
-            float v[7];
-#pragma unroll
-            for (int c = 0; c < 3; c++) { v[c] = row[3 * w + c]; v[3 + c] = row[9 + 3 * w + c]; }
-            v[6] = row[18 + w];
-            if (slot >= 0) {
-#pragma unroll
-                for (int c = 0; c < 7; c++) atomicAdd(&L.vval[slot][c], (double)v[c]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 7; c++) atomicAdd(&vrow[(int64_t)rid * VROW + c], v[c]);
-            }
-        } else {
-            const uint32_t rid = (uint32_t)sb * (uint32_t)p.F + (uint32_t)__float_as_int(row[26]);
-            atomicAdd(&frow[(int64_t)rid * FROW], row[21]); atomicAdd(&frow[(int64_t)rid * FROW + 1], row[22]);
-        }
-    }
-    wave_lds_sync();  // the stage area may be refilled
-}
-
 // One workgroup per tile (longest list first), one lane per GROUP of HIT_GROUP consecutive records -- all of one list
 // entry, because k_tri_backward_pix pads every face's run to a multiple of HIT_GROUP.  The lane gathers its face once,
-// sums the 23 components of its (up to) HIT_GROUP pairs in registers, and only then enters the segmented scan: one scan,
+// sums the 21 components of its (up to) HIT_GROUP pairs in registers, and only then enters the segmented scan: one scan,
 // one tail hand-off per group instead of per record (the scan was 92 half-rate DPP instructions of ~600 per 64 records),
 // and HIT_GROUP independent pixel gathers in flight per lane.
 #ifndef DMR_HITS_WAVES
@@ -820,7 +793,7 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     const int b = tile / (p.gx * p.gy);
 
     __shared__ HitsLds L;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     DMR_STAMP_RT(p, 2, 0);
     DMR_STAMP(p, 2, 0u, 8);
     const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};
@@ -862,13 +835,16 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         load_group(gi + 256u, nxt);  // in flight while this round computes (past the end: nothing is loaded)
         int k = -1 - lane;  // invalid lanes: unique keys
         int v0 = 0, v1 = 0, v2 = 0, face = 0;
-        float g[NACC];
+        float g[NSCAN];
 #pragma unroll
-        for (int c = 0; c < NACC; c++) g[c] = 0.f;
+        for (int c = 0; c < NSCAN; c++) g[c] = 0.f;
         if (valid) {  // key and row ids: a group of skipped pairs at the end of its run still carries the run's sums to the tables
             face = (int)raw[0].x; v0 = (int)raw[1].x; v1 = (int)raw[2].x; v2 = (int)raw[3].x;
             k = face;  // a face occurs once per tile: as good a segment key as the list entry
         }
+        // the face's ray-independent vectors: needed by the pairs below and, after the scan, by the segment tails
+        V3 xT = {0.f, 0.f, 0.f}, xE1 = xT, xE2 = xT, xQ = xT, xE12 = xT, xE2T = xT;
+        float w2 = 0.f;
         if (valid) {
             using namespace fm;
             // the face, once per group
@@ -877,10 +853,13 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             const float fd0 = p.vproj[(int64_t)b * p.P + v0].w, fd1 = p.vproj[(int64_t)b * p.P + v1].w,
                         fd2 = p.vproj[(int64_t)b * p.P + v2].w;
             const V3 xp0 = load_v3(p.verts, v0), xp1 = load_v3(p.verts, v1), xp2 = load_v3(p.verts, v2);
-            const V3 xT = view_o - xp0, xE1 = xp1 - xp0, xE2 = xp2 - xp0;
-            const V3 xQ = dmr::cross(xT, xE1);
-            const float w2 = dmr::dot(xQ, xE2);
-            const V3 xE12 = dmr::cross(xE1, xE2), xE2T = dmr::cross(xE2, xT);
+            xT = view_o - xp0; xE1 = xp1 - xp0; xE2 = xp2 - xp0;
+            xQ = dmr::cross(xT, xE1);
+            w2 = dmr::dot(xQ, xE2);
+            xE12 = dmr::cross(xE1, xE2); xE2T = dmr::cross(xE2, xT);
+            // i0 = 1 - uc - vc, i1 = uc, i2 = vc: what multiplies uc and vc in the interpolated colour / depth
+            const F3 dc10 = cc1 - cc0, dc20 = cc2 - cc0;
+            const float dd10 = fd1 - fd0, dd20 = fd2 - fd0;
 #ifdef DMR_ABLATION
             if (DMR_DBG(p, 4096)) {  // (phase stamps: the face's gathers have arrived)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -915,48 +894,52 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
                 const float aT = alpha * hT;
                 const float dic0 = pr1.x * aT, dic1 = pr1.y * aT, dic2 = pr1.z * aT, did = pr0.w * aT;
                 const float dii0 = dic0 * intense, dii1 = dic1 * intense, dii2 = dic2 * intense;
-                // dL/d(barycentric weights) (backward.cu:313-330)
-                const float dL_di0 = cc0.x * dii0 + cc0.y * dii1 + cc0.z * dii2 + fd0 * did;
-                const float dL_di1 = cc1.x * dii0 + cc1.y * dii1 + cc1.z * dii2 + fd1 * did;
-                const float dL_di2 = cc2.x * dii0 + cc2.y * dii1 + cc2.z * dii2 + fd2 * did;
-                const float dfint = (i0 * cc0.x + i1 * cc1.x + i2 * cc2.x) * dic0 + (i0 * cc0.y + i1 * cc1.y + i2 * cc2.y) * dic1
-                                  + (i0 * cc0.z + i1 * cc1.z + i2 * cc2.z) * dic2;
-                // through the clamp (i0 = 1 - uc - vc, i1 = uc, i2 = vc; Jacobian of auxiliary.h:374-400)
+                // dL/d(uc), dL/d(vc) (backward.cu:313-330: dL/d(weights), then i1 - i0 and i2 - i0) and dL/dintensity
+                const float e1 = dc10.x * dii0 + dc10.y * dii1 + dc10.z * dii2 + dd10 * did;
+                const float e2 = dc20.x * dii0 + dc20.y * dii1 + dc20.z * dii2 + dd20 * did;
+                const float dfint = (cc0.x + iuc * dc10.x + ivc * dc20.x) * dic0 + (cc0.y + iuc * dc10.y + ivc * dc20.y) * dic1
+                                  + (cc0.z + iuc * dc10.z + ivc * dc20.z) * dic2;
+                // through the clamp (Jacobian of auxiliary.h:374-400)
                 float duc_du, duc_dv, dvc_du, dvc_dv;
                 clamp_bary_uv_grad(code, duc_du, duc_dv, dvc_du, dvc_dv);
-                const float e1 = dL_di1 - dL_di0, e2 = dL_di2 - dL_di0;
                 const float dL_diu = e1 * duc_du + e2 * dvc_du;
                 const float dL_div = e1 * duc_dv + e2 * dvc_dv;
-                // ray_tri_intersection_grad (auxiliary.h:288-333; Q11: the "v" numerator is t's, Q12: no clamp of
-                // denom^2) in the reference's own order of operations and without contraction (the V3 helpers): for a
-                // grazing ray 1 / denom^2 is huge and the six derivative vectors are differences of nearly equal terms,
-                // so this part stays bit-comparable with the oracle.
-                const float dinv = 1.0f / (denom * denom);
-                const float w0 = nu, w1 = denom;
-                const V3 du_dE1 = (-1.0f * xP * w0) * dinv;
-                const V3 du_dE2 = (dmr::cross(xT, xd) * w1 - w0 * dmr::cross(xE1, xd)) * dinv;
-                const V3 du_dT = (xP * w1) * dinv;
-                const V3 dv_dE1 = ((xE2T * w1) - (w2 * xP)) * dinv;
-                const V3 dv_dE2 = ((xQ * w1) - (w2 * dmr::cross(xE1, xd))) * dinv;
-                const V3 dv_dT = xE12 * w1 * dinv;
-                const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
-                const V3 dp0 = dL_diu * du_dp0 + dL_div * dv_dp0;
-                const V3 dp1 = dL_diu * du_dE1 + dL_div * dv_dE1;
-                const V3 dp2 = dL_diu * du_dE2 + dL_div * dv_dE2;
-                float h[NACC];
-                h[0] = dp0.x; h[1] = dp0.y; h[2] = dp0.z;
-                h[3] = dp1.x; h[4] = dp1.y; h[5] = dp1.z;
-                h[6] = dp2.x; h[7] = dp2.y; h[8] = dp2.z;
-                h[9] = i0 * dii0; h[10] = i0 * dii1; h[11] = i0 * dii2;
-                h[12] = i1 * dii0; h[13] = i1 * dii1; h[14] = i1 * dii2;
-                h[15] = i2 * dii0; h[16] = i2 * dii1; h[17] = i2 * dii2;
-                h[18] = i0 * did; h[19] = i1 * did; h[20] = i2 * did;
-                h[21] = hdLda; h[22] = dfint;
-                // The scan below multiplies neighbours' partial sums by 0/1 masks, so a non-finite value must not enter
-                // it (0 * inf = NaN would leak into the next list entry).  Such a pair (degenerate face, Q12; opacity
+                const float dinv = inv_denom * inv_denom;
+                // The sums below multiply neighbours' partial sums by 0/1 masks in the scan, so a non-finite value must not
+                // enter them (0 * inf = NaN would leak into the next list entry).  Such a pair (degenerate face, Q12; opacity
                 // exactly 1 behind it) adds its values with plain atomics, as the reference does for every pair.
                 const float chk = (dinv * 0.f) + (aT * 0.f) + (hdLda * 0.f);
                 if (!(chk == 0.f)) {
+                    // ray_tri_intersection_grad as the reference writes it (auxiliary.h:288-333; Q11: the "v" numerator
+                    // is t's, Q12: no clamp of denom^2), pair by pair
+                    const float dL_di0 = cc0.x * dii0 + cc0.y * dii1 + cc0.z * dii2 + fd0 * did;
+                    const float dL_di1 = cc1.x * dii0 + cc1.y * dii1 + cc1.z * dii2 + fd1 * did;
+                    const float dL_di2 = cc2.x * dii0 + cc2.y * dii1 + cc2.z * dii2 + fd2 * did;
+                    const float f1 = dL_di1 - dL_di0, f2 = dL_di2 - dL_di0;
+                    const float rdiu = f1 * duc_du + f2 * dvc_du, rdiv = f1 * duc_dv + f2 * dvc_dv;
+                    const float rinv = 1.0f / (denom * denom);
+                    const float w0 = nu, w1 = denom;
+                    const V3 du_dE1 = (-1.0f * xP * w0) * rinv;
+                    const V3 du_dE2 = (dmr::cross(xT, xd) * w1 - w0 * dmr::cross(xE1, xd)) * rinv;
+                    const V3 du_dT = (xP * w1) * rinv;
+                    const V3 dv_dE1 = ((xE2T * w1) - (w2 * xP)) * rinv;
+                    const V3 dv_dE2 = ((xQ * w1) - (w2 * dmr::cross(xE1, xd))) * rinv;
+                    const V3 dv_dT = xE12 * w1 * rinv;
+                    const V3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
+                    const V3 dp0 = rdiu * du_dp0 + rdiv * dv_dp0;
+                    const V3 dp1 = rdiu * du_dE1 + rdiv * dv_dE1;
+                    const V3 dp2 = rdiu * du_dE2 + rdiv * dv_dE2;
+                    float h[NACC];
+                    h[0] = dp0.x; h[1] = dp0.y; h[2] = dp0.z;
+                    h[3] = dp1.x; h[4] = dp1.y; h[5] = dp1.z;
+                    h[6] = dp2.x; h[7] = dp2.y; h[8] = dp2.z;
+                    h[9] = i0 * dii0; h[10] = i0 * dii1; h[11] = i0 * dii2;
+                    h[12] = i1 * dii0; h[13] = i1 * dii1; h[14] = i1 * dii2;
+                    h[15] = i2 * dii0; h[16] = i2 * dii1; h[17] = i2 * dii2;
+                    h[18] = i0 * did; h[19] = i1 * did; h[20] = i2 * did;
+                    h[21] = hdLda;
+                    h[22] = (i0 * cc0.x + i1 * cc1.x + i2 * cc2.x) * dic0 + (i0 * cc0.y + i1 * cc1.y + i2 * cc2.y) * dic1
+                          + (i0 * cc0.z + i1 * cc1.z + i2 * cc2.z) * dic2;
                     float* r0 = vrow + ((int64_t)b * p.P + v0) * VROW; float* r1 = vrow + ((int64_t)b * p.P + v1) * VROW;
                     float* r2 = vrow + ((int64_t)b * p.P + v2) * VROW; float* rf = frow + ((int64_t)b * p.F + face) * FROW;
 #pragma unroll
@@ -967,8 +950,24 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
                     atomicAdd(r0 + 6, h[18]); atomicAdd(r1 + 6, h[19]); atomicAdd(r2 + 6, h[20]);
                     atomicAdd(rf, h[21]); atomicAdd(rf + 1, h[22]);
                 } else {
-#pragma unroll
-                    for (int c = 0; c < NACC; c++) g[c] += h[c];
+                    // The vertex-position gradient of ray_tri_intersection_grad is LINEAR in the ray direction d once the
+                    // pair's scalars are fixed -- every d enters through d x E2, T x d or E1 x d:
+                    //   dL/dp1 = S3 E2T - B x E2,   dL/dp2 = T x A2 - E1 x B + S3 Q,   dL/dT = A2 x E2 + S3 E12,
+                    //   dL/dp0 = -(dL/dp1 + dL/dp2 + dL/dT)
+                    // with s2 = dL/du / denom, s3 = dL/dv / denom, B = sum (s2 nu + s3 w2) / denom * d, A2 = sum s2 d,
+                    // S3 = sum s3 (w2 = Q . E2 is the reference's "v" numerator, Q11).  So a pair adds 7 multiply-adds here
+                    // and the six cross products are taken once per list entry, at the segment tails after the scan -- not
+                    // ~150 instructions per pair.  Rounding: (s d) x E2 and s (d x E2) lose the same bits.
+                    const float s2 = dL_diu * inv_denom, s3 = dL_div * inv_denom;
+                    const float sb = (s2 * nu + s3 * w2) * inv_denom;
+                    g[0] += sb * xd.x; g[1] += sb * xd.y; g[2] += sb * xd.z;
+                    g[3] += s2 * xd.x; g[4] += s2 * xd.y; g[5] += s2 * xd.z;
+                    g[6] += s3;
+                    g[7] += i0 * dii0; g[8] += i0 * dii1; g[9] += i0 * dii2;
+                    g[10] += i1 * dii0; g[11] += i1 * dii1; g[12] += i1 * dii2;
+                    g[13] += i2 * dii0; g[14] += i2 * dii1; g[15] += i2 * dii2;
+                    g[16] += i0 * did; g[17] += i1 * did; g[18] += i2 * did;
+                    g[19] += hdLda; g[20] += dfint;
                 }
             }
         }
@@ -981,22 +980,42 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
         seg_scan_level<DPP_ROW_SHR + 4, 0xF>(k, g);
         seg_scan_level<DPP_ROW_SHR + 8, 0xF>(k, g);
 
-        // segment tails hold the totals: stage them (wave-private LDS), 16 at a time, and add them into the table
+        // segment tails hold the totals: the ray moments become the three vertex-position gradients (see above)
         DMR_STAMP(p, 2, g0 / 256u, 3);
         const int kn = __shfl_down(k, 1, 64);
         const bool tail = valid && ((lane & 15) == 15 || kn != k);
-        const uint64_t tmask = __ballot(tail);
-        const int ntail = __popcll(tmask);
-        const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-        for (int t0 = 0; t0 < ntail; t0 += STAGE_SEGS) {
-            if (tail && rank >= t0 && rank < t0 + STAGE_SEGS) {
-                float* st = L.stage[wave][rank - t0];
+        fm::F3 dp0, dp1, dp2;
+        {
+            using namespace fm;
+            const F3 mB = {g[0], g[1], g[2]}, mA = {g[3], g[4], g[5]};
+            const F3 fT = {xT.x, xT.y, xT.z}, fE1 = {xE1.x, xE1.y, xE1.z}, fE2 = {xE2.x, xE2.y, xE2.z};
+            const F3 fQ = {xQ.x, xQ.y, xQ.z}, fE12 = {xE12.x, xE12.y, xE12.z}, fE2T = {xE2T.x, xE2T.y, xE2T.z};
+            dp1 = g[6] * fE2T - cross(mB, fE2);
+            dp2 = cross(fT, mA) - cross(fE1, mB) + g[6] * fQ;
+            const F3 dT = cross(mA, fE2) + g[6] * fE12;
+            dp0 = -(dp1 + dp2 + dT);
+        }
+        // a tail lane adds its entry's three vertex rows into the table and sends the face row out, from its registers
+        if (tail && !DMR_DBG(p, 512)) {
+            const float rows[3][7] = {{dp0.x, dp0.y, dp0.z, g[7], g[8], g[9], g[16]},
+                                      {dp1.x, dp1.y, dp1.z, g[10], g[11], g[12], g[17]},
+                                      {dp2.x, dp2.y, dp2.z, g[13], g[14], g[15], g[18]}};
+            const int vid[3] = {v0, v1, v2};
 #pragma unroll
-                for (int c = 0; c < NACC; c++) st[c] = g[c];
-                st[23] = __int_as_float(v0); st[24] = __int_as_float(v1); st[25] = __int_as_float(v2);
-                st[26] = __int_as_float(face); st[27] = __int_as_float(b);
+            for (int w = 0; w < 3; w++) {
+                const uint32_t rid = (uint32_t)b * (uint32_t)p.P + (uint32_t)vid[w];
+                // (ablation build, DMR_ABLATE bit 2048, tests only: odd rows are refused a slot, which exercises the direct-atomic fallback)
+                const int slot = (DMR_DBG(p, 2048) && (rid & 1u)) ? -1 : tab_find<VTAB>(L.vkey, rid);
+                if (slot >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 7; c++) atomicAdd(&L.vval[slot][c], (double)rows[w][c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 7; c++) atomicAdd(&vrow[(int64_t)rid * VROW + c], rows[w][c]);
+                }
             }
-            if (!DMR_DBG(p, 512)) accumulate_staged(p, L, wave, lane, min(STAGE_SEGS, ntail - t0), vrow, frow);
+            const int64_t fid = (int64_t)b * p.F + face;
+            atomicAdd(&frow[fid * FROW], g[19]); atomicAdd(&frow[fid * FROW + 1], g[20]);
         }
         DMR_STAMP(p, 2, g0 / 256u, 4);
     }

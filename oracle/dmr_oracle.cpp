@@ -169,6 +169,37 @@ inline void ray_tri_intersection_grad(f3 o, f3 d, f3 p0, f3 p1, f3 p2,
     du_dp2 = du_dE2; dv_dp2 = dv_dE2;
 }
 
+// The same function evaluated in double (inputs promoted, outputs rounded once): not a reference behaviour.  It
+// measures how much of a dL_dverts entry is float rounding noise of the reference's own arithmetic -- cross(T, d) loses
+// |T| / (distance of p0 from the ray) ~ 1e2..1e4 in relative precision -- which bounds how closely ANY other float
+// evaluation order can agree with the restatement above (dmro_set_tri_grad_f64, tests/tools/grad_noise.py).
+struct d3 { double x, y, z; };
+inline d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline d3 operator-(d3 a) { return {-a.x, -a.y, -a.z}; }
+inline d3 operator*(d3 a, double b) { return {a.x * b, a.y * b, a.z * b}; }
+inline d3 operator*(double b, d3 a) { return {b * a.x, b * a.y, b * a.z}; }
+inline double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline d3 cross(d3 a, d3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline d3 up(f3 a) { return {a.x, a.y, a.z}; }
+inline void tri_dverts_f64(f3 o_, f3 d_, f3 p0_, f3 p1_, f3 p2_, float dL_diu, float dL_div, d3& dp0, d3& dp1, d3& dp2) {
+    const d3 o = up(o_), d = up(d_), p0 = up(p0_), p1 = up(p1_), p2 = up(p2_);
+    const d3 T = o - p0, E1 = p1 - p0, E2 = p2 - p0;
+    const double v1 = dot(cross(d, E2), E1), denom_inv = 1.0 / (v1 * v1);
+    const double v0 = dot(cross(d, E2), T), v2 = dot(cross(T, E1), E2);
+    const d3 du_dE1 = (-1.0 * cross(d, E2) * v0) * denom_inv;
+    const d3 du_dE2 = (cross(T, d) * v1 - v0 * cross(E1, d)) * denom_inv;
+    const d3 du_dT = (cross(d, E2) * v1) * denom_inv;
+    const d3 dv_dE1 = ((cross(E2, T) * v1) - (v2 * cross(d, E2))) * denom_inv;
+    const d3 dv_dE2 = ((cross(T, E1) * v1) - (v2 * cross(E1, d))) * denom_inv;
+    const d3 dv_dT = cross(E1, E2) * v1 * denom_inv;
+    const d3 du_dp0 = -du_dE1 - du_dE2 - du_dT, dv_dp0 = -dv_dE1 - dv_dE2 - dv_dT;
+    dp0 = (double)dL_diu * du_dp0 + (double)dL_div * dv_dp0;
+    dp1 = (double)dL_diu * du_dE1 + (double)dL_div * dv_dE1;
+    dp2 = (double)dL_diu * du_dE2 + (double)dL_div * dv_dE2;
+}
+static int g_tri_grad_f64 = 0;
+
 // auxiliary.h:335-372
 inline void clamp_bary_uv(float u, float v, float& u_c, float& v_c, int& code) {
     if (u >= 0.0f && v >= 0.0f && u + v <= 1.0f) { u_c = u; v_c = v; code = 0; }
@@ -661,9 +692,17 @@ void tri_backward_tile(const dmro_scene* s, const dmro_state* st, int b, int ty,
                 f3 dp1 = dL_diu * du1 + dL_div * dv1;
                 f3 dp2 = dL_diu * du2 + dL_div * dv2;
 
+                if (g_tri_grad_f64) {  // (noise measurement only, see tri_dverts_f64)
+                    d3 q0, q1, q2;
+                    tri_dverts_f64(ro, rd, r.p0, r.p1, r.p2, dL_diu, dL_div, q0, q1, q2);
+                    g.dverts[3 * r.v0] += q0.x; g.dverts[3 * r.v0 + 1] += q0.y; g.dverts[3 * r.v0 + 2] += q0.z;
+                    g.dverts[3 * r.v1] += q1.x; g.dverts[3 * r.v1 + 1] += q1.y; g.dverts[3 * r.v1 + 2] += q1.z;
+                    g.dverts[3 * r.v2] += q2.x; g.dverts[3 * r.v2 + 1] += q2.y; g.dverts[3 * r.v2 + 2] += q2.z;
+                } else {
                 g.dverts[3 * r.v0] += dp0.x; g.dverts[3 * r.v0 + 1] += dp0.y; g.dverts[3 * r.v0 + 2] += dp0.z;
                 g.dverts[3 * r.v1] += dp1.x; g.dverts[3 * r.v1 + 1] += dp1.y; g.dverts[3 * r.v1 + 2] += dp1.z;
                 g.dverts[3 * r.v2] += dp2.x; g.dverts[3 * r.v2 + 1] += dp2.y; g.dverts[3 * r.v2 + 2] += dp2.z;
+                }
                 for (int k = 0; k < 3; k++) {
                     g.dvcolor[3 * r.v0 + k] += dvc0[k];
                     g.dvcolor[3 * r.v1 + k] += dvc1[k];
@@ -981,6 +1020,7 @@ int64_t copy_out(const std::vector<T>& v, void* dst, int64_t cap) {
 extern "C" {
 
 const char* dmro_last_error(void) { return g_err.c_str(); }
+void dmro_set_tri_grad_f64(int on) { g_tri_grad_f64 = on; }
 
 int dmro_num_threads(void) {
 #ifdef _OPENMP

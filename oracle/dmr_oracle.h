@@ -90,6 +90,9 @@ void dmro_rect_from_tri(const float* p0, const float* p1, const float* p2, int g
 uint32_t dmro_higher_msb(uint32_t n);
 
 const char* dmro_last_error(void);
+/* Noise measurement only (tests/tools/grad_noise.py): non-zero = dmro_tri_backward evaluates the vertex-position gradient of
+ * every (pixel, face) pair in double (same formula, float inputs) instead of in the reference's float arithmetic. */
+void dmro_set_tri_grad_f64(int on);
 int dmro_num_threads(void);
 
 #ifdef __cplusplus

@@ -61,6 +61,8 @@ def lib():
         L.dmro_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
         L.dmro_free.argtypes = [C.c_void_p]
         L.dmro_last_error.restype = C.c_char_p
+        L.dmro_set_tri_grad_f64.restype = None
+        L.dmro_set_tri_grad_f64.argtypes = [C.c_int]
         L.dmro_num_threads.restype = C.c_int
         L.dmro_in_tri.restype = C.c_int
         L.dmro_in_tri.argtypes = [C.c_float] * 8
@@ -169,8 +171,10 @@ def tri_forward(sc: Scene):
     return color, depth, State(h, sc)
 
 
-def tri_backward(sc: Scene, st: State, dL_dcolor, dL_ddepth) -> Dict[str, np.ndarray]:
+def tri_backward(sc: Scene, st: State, dL_dcolor, dL_ddepth, verts_grad_f64: bool = False) -> Dict[str, np.ndarray]:
+    """verts_grad_f64 (noise measurement only): the per-pair vertex-position gradient is evaluated in double."""
     gc, gd = _f32(dL_dcolor), _f32(dL_ddepth)
+    lib().dmro_set_tri_grad_f64(1 if verts_grad_f64 else 0)
     out = {
         "verts": np.empty((sc.P, 3), np.float32), "verts_color": np.empty((sc.P, 3), np.float32),
         "faces_opacity": np.empty((sc.F,), np.float32), "verts_depth": np.empty((sc.B, sc.P), np.float32),
@@ -178,6 +182,7 @@ def tri_backward(sc: Scene, st: State, dL_dcolor, dL_ddepth) -> Dict[str, np.nda
     }
     rc = lib().dmro_tri_backward(C.byref(sc.c), st.h, gc.ctypes.data, gd.ctypes.data,
                                  *[out[k].ctypes.data for k in ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")])
+    lib().dmro_set_tri_grad_f64(0)
     if rc:
         raise _err()
     return out

@@ -16,7 +16,7 @@ import pytest
 import torch as th
 
 from dmesh_renderer_amd import scenes
-from util import c_args, elementwise_close, rel_err, upstream_grads
+from util import SUM_ORDER_TOL, c_args, elementwise_close, rel_err, upstream_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -110,8 +110,8 @@ def test_c4_backward_linear_and_repeatable(c4):
     g1b = _C.render_tris_backward(*args, c4["gc"], c4["gd"], out[0], *out[3:7])
     g2 = _C.render_tris_backward(*args, 2.0 * c4["gc"], 2.0 * c4["gd"], out[0], *out[3:7])
     for a, b, c, k in zip(g1, g1b, g2, NAMES):
-        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 1e-5, k      # float atomics: order may differ
-        assert rel_err(c.cpu().numpy(), 2.0 * a.cpu().numpy()) <= 1e-5, k
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= SUM_ORDER_TOL, k      # float sums: order may differ
+        assert rel_err(c.cpu().numpy(), 2.0 * a.cpu().numpy()) <= SUM_ORDER_TOL, k
 
 
 def test_c4_bands_compose(c4):
@@ -132,7 +132,7 @@ def test_c4_bands_compose(c4):
     assert rsum == out[0]
     assert th.equal(color, out[1]) and th.equal(depth, out[2])
     for a, b, k in zip(gsum, gfull, NAMES):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, k
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= SUM_ORDER_TOL, k
 
 
 def test_matrix_layouts_agree(hip_device):
@@ -160,7 +160,7 @@ def test_matrix_layouts_agree(hip_device):
     ac = [t.contiguous() if i in (5, 6, 7, 8) else t for i, t in enumerate(args)]
     g1 = _C.render_tris_backward(*ac, gc.to(hip_device), gd.to(hip_device), ref[0], *ref[3:7])
     for x, y in zip(g0, g1):
-        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) <= 1e-5
+        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) <= SUM_ORDER_TOL
 
 
 def test_c3_tet_matches_oracle_and_repeats(hip_device, oracle):
@@ -297,4 +297,4 @@ def test_four_views_1080p(hip_device, oracle):
             a += b
     assert th.equal(color, out[1])
     for a, b, k in zip(gsum, g, NAMES):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, k
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= SUM_ORDER_TOL, k

@@ -20,3 +20,6 @@ for it in range(2):
         e = np.abs(a - r); i = np.unravel_index(np.argmax(e), e.shape)
         print(f"{k:14s} rel {e.max() / max(1, np.abs(r).max()):.3e} maxabs ref {np.abs(r).max():.3e} worst at {i}: got {a[i]:.6e} ref {r[i]:.6e}; "
               f"n(|err|>1e-4*max) = {(e > 1e-4 * max(1, np.abs(r).max())).sum()} nan {np.isnan(a).sum()}")
+        lim = 2e-6 * max(1, np.abs(r).max()) + 1e-3 * np.abs(r); q = e / lim; j = np.unravel_index(np.argmax(q), q.shape)
+        print(f"{'':14s} per entry (2e-6 max + 1e-3 |ref|): worst ratio {q.max():.3f} at {j}: got {a[j]:.6e} ref {r[j]:.6e}; n(ratio > 1) = {(q > 1).sum()}"
+              f"; n(ratio > 0.5) = {(q > 0.5).sum()}")
