@@ -29,7 +29,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdmesh_renderer_hip.so")
 LIB_ABLATION = os.path.join(HERE, "libdmesh_renderer_hip_ablation.so")
 SOURCES = ["dmr_api.hip", "dmr_binning.hip", "dmr_tri.hip", "dmr_tet.hip"]
-HEADERS = ["dmr_device.hpp", "dmr_kernels.hpp", os.path.join("..", "..", "include", "dmesh_renderer_amd.h")]
+HEADERS = ["dmr_device.hpp", "dmr_kernels.hpp", "dmr_sort.hpp", os.path.join("..", "..", "include", "dmesh_renderer_amd.h")]
 ARCH = "gfx950"
 
 

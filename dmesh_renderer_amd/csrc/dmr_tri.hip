@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "dmr_kernels.hpp"
+#include "dmr_sort.hpp"
 
 namespace dmr {
 
@@ -92,6 +93,7 @@ struct TriParams {
     const float* verts; const int* faces; const float* verts_color; const float* faces_opacity;
     const float* inv_mv; const float* inv_proj; const float* faces_intense; const float* bg;
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
+    unsigned long long* keys;  // (depth_bits << 32 | face) of every list entry, unsorted: the forward sorts its tile's
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
     uint32_t* tile_hits; const uint32_t* hit_offset; uint32_t* tile_used; const uint32_t* tile_order;
     const unsigned long long* mask_offset;  // coverage masks: byte offset behind face_list (TriImageState)
@@ -234,14 +236,23 @@ __device__ __forceinline__ void rasterize_faces(const CovRec* __restrict__ cov, 
 #ifndef DMR_PIX_WAVES
 #define DMR_PIX_WAVES 6
 #endif
+// The workgroup first SORTS its tile's list (dmr_sort.hpp; the LDS of the sort is the LDS of the compositing loop): as a
+// kernel of its own the sort took 22-24 us at C4, nearly all of it the serial chain of the longest tile on an otherwise
+// idle chip (an eighth of the tiles took 19 us, profiles/r02/shard_kernel_sums_c4.json); here that chain runs beside the
+// other workgroups' compositing.  The sorted ids go to face_list for this kernel's own staging (a block's global writes
+// are visible to it behind a barrier) and for the backward.
 template <int CHUNK>
 __global__ void __launch_bounds__(256, DMR_FWD_WAVES)
 k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ out_depth) {
     constexpr int WORDS = CHUNK / 32;
     static_assert(WORDS == 4, "one 32-face block per wave");
-    __shared__ CovRec s_cov[CHUNK];
-    __shared__ ShadeRec s_shade[CHUNK];
-    __shared__ uint32_t s_pm[TILE_PIX][WORDS];  // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
+    constexpr int COV_BYTES = CHUNK * (int)sizeof(CovRec), SHADE_BYTES = CHUNK * (int)sizeof(ShadeRec);
+    constexpr int FWD_BYTES = COV_BYTES + SHADE_BYTES + TILE_PIX * WORDS * (int)sizeof(uint32_t);
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[FWD_BYTES > SORT_LDS_BYTES ? FWD_BYTES : SORT_LDS_BYTES];
+    CovRec* const s_cov = reinterpret_cast<CovRec*>(s_mem);
+    ShadeRec* const s_shade = reinterpret_cast<ShadeRec*>(s_mem + COV_BYTES);
+    // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
+    uint32_t (*const s_pm)[WORDS] = reinterpret_cast<uint32_t (*)[WORDS]>(s_mem + COV_BYTES + SHADE_BYTES);
     __shared__ uint32_t s_live[2];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -270,6 +281,10 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         }
         return;  // uniform
     }
+
+    sort_tile(begin, end - begin, reinterpret_cast<uint64_t*>(p.keys), const_cast<uint32_t*>(p.face_list),
+              reinterpret_cast<uint64_t*>(s_mem), reinterpret_cast<uint32_t*>(s_mem + SORT_LDS_KEYS * sizeof(uint64_t)), (uint32_t)tid);
+    __syncthreads();  // face_list[begin, end) is sorted and visible to this workgroup; the LDS is free
 
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside && !DMR_DBG(p, 32)) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
@@ -1083,7 +1098,7 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
 #endif
     p.verts = s.verts; p.faces = s.faces; p.verts_color = s.verts_color; p.faces_opacity = s.faces_opacity;
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
-    p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list;
+    p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list; p.keys = nullptr;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
     p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset; p.tile_used = img.tile_used; p.tile_order = img.tile_order;
     p.mask_offset = img.mask_offset;
@@ -1092,10 +1107,11 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
 }
 
 void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
-                        const uint32_t* tile_offset, const uint32_t* face_list, uint32_t capacity, TriImageState img,
+                        const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, uint32_t capacity, TriImageState img,
                         float* out_color, float* out_depth, hipStream_t st) {
     if (r1 <= r0) return;
     TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
+    p.keys = reinterpret_cast<unsigned long long*>(keys);
     p.list_capacity = capacity;
     StageScope t(DMR_STAGE_TRI_FORWARD, st);
     k_tri_forward<FWD_CHUNK><<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, out_color, out_depth);
