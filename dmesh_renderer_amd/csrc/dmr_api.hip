@@ -50,7 +50,7 @@ struct FaceState { uint2* rect; float* key_depth; float* max_depth; uint32_t* ti
 struct ImageState {
     uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_cursor; int* num_rendered;
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits; uint32_t* scan_tmp; uint32_t* hit_offset; uint32_t* tile_used; unsigned long long* hit_total; uint32_t* tile_order;
+    uint32_t* tile_hits; uint32_t* tile_bound; uint32_t* scan_tmp; uint32_t* hit_offset; uint32_t* tile_used; unsigned long long* hit_total; uint32_t* tile_order;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
     int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
@@ -77,8 +77,8 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
     s.mats = c.take<float>(64 * B);
     s.seed = c.take<int>(1);
     s.mask_offset = c.take<unsigned long long>(1);
-    // counters, zeroed by k_project_verts at the start of a forward: [tile_count | tile_hits | scan_tmp's buckets]
-    s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles);
+    // counters, zeroed by k_project_verts at the start of a forward: [tile_count | tile_hits | tile_bound | scan_tmp's buckets]
+    s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles); s.tile_bound = c.take<uint32_t>(ntiles);
     s.scan_tmp = c.take<uint32_t>(dmr::scan_tmp_words((int)ntiles));
     s.hit_offset = c.take<uint32_t>(ntiles + 1); s.tile_used = c.take<uint32_t>(ntiles); s.hit_total = c.take<unsigned long long>(1);
     s.tile_offset = c.take<uint32_t>(ntiles + 1);
@@ -224,7 +224,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     // host_R: pinned slot the scan also stores R into (null: not needed).  Not on a redo pass: R is known by then, and
     // a late store could land in the slot after this call has returned and a later call (another stream) reuses it.
     auto front = [&](int* host_R, uint64_t capacity, uint32_t* ovf) -> int {
-        // (tile_count | tile_hits are contiguous: zeroed by k_project_verts, a slice per block)
+        // (tile_count | tile_hits | tile_bound are contiguous: zeroed by k_project_verts, a slice per block)
         dmr::launch_project_verts(*s, ps.vproj, is.mats, is.tile_count, (size_t)(is.scan_tmp + dmr::SCAN_TMP_BUCKETS - is.tile_count), st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
@@ -381,7 +381,7 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.tile_bound, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.keys, bs.face_list, bs.capacity, img, out_color,
                                 out_depth, st);
@@ -423,7 +423,9 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     uint32_t* overflow = overflow_word(dev, !async);
     const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
     const size_t pbytes = up(sizeof(float4) * 2 * (size_t)d.ntiles * dmr::TILE_PIX);  // per tile: its 256 pixels' (ray, upstream gradient) records
-    auto rest = [&](uint64_t capacity) -> int {
+    // regions: see dmr::HitRegions -- null hit_offset: launch_scan_hits has laid the record regions out.  after_pix: called
+    // between the per-pixel and the hit-parallel launch (the event behind which the record total is on the host).
+    auto rest = [&](uint64_t capacity, dmr::HitRegions regions, const std::function<int()>& after_pix) -> int {
         const size_t hbytes = up(sizeof(dmr::HitRecord) * (size_t)capacity);
         char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes + pbytes + hbytes));
         if (!work) return fail("workspace allocation failed");
@@ -431,21 +433,25 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         float* frow = reinterpret_cast<float*>(work + vbytes);
         float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
         dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.tile_bound, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
         const dmr_scene sc = canonical(s, is.mats);
         // (Splitting the tiles into bands whose hit-parallel kernel runs on a second stream while the next band's
         // per-pixel kernel computes -- atomic unit and SIMDs busy at the same time -- was measured and lost: 0.56 ms
         // per step with 1 band, 0.64 with 2, 0.70 with 4 at C4; cross-stream event waits cost more than the overlap.)
         // k_tri_backward_pix also zeroes the packed accumulators (every block a slice).  (Handing out the tiles'
-        // record regions from an atomic cursor instead of k_scan_hits: the 2.9 k returning same-address atomics
-        // stall their waves, in order with every younger load -- 17 us against the scan's 6.)
+        // record regions from an atomic cursor: the 2.9 k returning same-address atomics stall their waves, in order
+        // with every younger load -- 17 us.)
         dmr::launch_tri_backward_pix(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img,
                                      dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity,
-                                     reinterpret_cast<float*>(work), (vbytes + fbytes) / sizeof(float), st);
+                                     reinterpret_cast<float*>(work), (vbytes + fbytes) / sizeof(float), regions, st);
+        if (after_pix && after_pix()) return 1;
         dmr::launch_tri_backward_hits(sc, d.gx, d.gy, ps.vproj, bs.face_list, img, pixrec, hits, (uint32_t)capacity, vrow, frow, st);
         dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
         return 0;
     };
+    const dmr::HitRegions scanned{nullptr, nullptr, nullptr, nullptr};
+    // With a size estimate and few enough tiles the per-pixel kernel lays the regions out itself: no scan launch.
+    const bool self_regions = d.ntiles <= dmr::SCAN_SINGLE_MAX;
     const SizeKey key = size_key(s, false, d);
     uint64_t guess = 0;
     {
@@ -458,25 +464,37 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         if (!guess || !overflow)
             return fail("asynchronous / captured call without a size estimate: run one default (waiting) backward with the "
                         "same view configuration first");
-        dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, nullptr, is.scan_tmp, (uint32_t)guess, overflow, st);
-        if (rest(guess)) return 1;
+        if (self_regions) {
+            if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, overflow}, nullptr)) return 1;
+        } else {
+            dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, nullptr, is.scan_tmp, (uint32_t)guess, overflow, st);
+            if (rest(guess, scanned, nullptr)) return 1;
+        }
         DMR_HIP(hipGetLastError());
         return 0;
     }
     SizeRead* sr = size_read();
     if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
     unsigned long long* host_total = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sr->slot) + 8);
-    dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, host_total, is.scan_tmp, 0xffffffffu, nullptr, st);
-    DMR_HIP(hipEventRecord(sr->ev, st));
-    if (guess && rest(guess)) return 1;
+    auto record = [&]() -> int { DMR_HIP(hipEventRecord(sr->ev, st)); return 0; };
+    if (guess && self_regions) {
+        // everything is enqueued with the estimate; the total arrives behind the per-pixel kernel
+        if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, host_total, nullptr}, record)) return 1;
+    } else {
+        dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, host_total, is.scan_tmp, 0xffffffffu, nullptr, st);
+        if (record()) return 1;
+        if (guess && rest(guess, scanned, nullptr)) return 1;
+    }
     DMR_HIP(hipEventSynchronize(sr->ev));
     const unsigned long long nhits = *host_total;
     if (nhits >= 0xffffffffull) return fail("more than 2^32 blended (pixel, face) pairs");
     if (!guess) {
-        if (rest(nhits)) return 1;
-    } else if (nhits > guess) {
+        if (rest(nhits, scanned, nullptr)) return 1;
+    } else if (nhits > guess) {  // (the redo pass does not store into the pinned slot: a later call may own it by then)
         DMR_HIP(hipStreamSynchronize(st));
-        if (rest(nhits)) return 1;
+        if (self_regions) {
+            if (rest(nhits, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, nullptr}, nullptr)) return 1;
+        } else if (rest(nhits, scanned, nullptr)) return 1;
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);

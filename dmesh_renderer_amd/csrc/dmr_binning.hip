@@ -449,17 +449,13 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
 // per lane), so a tile with h blended pairs (counted by the forward) in a list of `len` entries needs at most
 // h + (HIT_GROUP - 1) * min(len, h) records; rounded up to whole blocks of HIT_BLOCK records (the layout inside a region,
 // dmr_kernels.hpp).
-__device__ __forceinline__ uint32_t record_bound(uint32_t h, uint32_t len) {
-    if (h == 0u) return 0u;
-    const uint32_t b = h + (uint32_t)(HIT_GROUP - 1) * min(len, h);
-    return (b + (uint32_t)(HIT_BLOCK - 1)) & ~(uint32_t)(HIT_BLOCK - 1);
-}
+// (record_bound: dmr_kernels.hpp)
 
 // ---- the same for many tiles (B * tiles > SCAN_SINGLE_MAX: several views at 1080p, 4096^2 images): one workgroup
 // per 8192 tiles, three small launches (partial sums + bucket sizes | scan of the partials | offsets + order) instead
 // of one workgroup streaming everything (0.5 ms for C5's 1 M tiles).
 constexpr int SCAN_BLOCK_TILES = 8192;
-constexpr int SCAN_SINGLE_MAX = SCAN_SLAB;   // up to here one workgroup does it all (k_scan_tiles, k_scan_hits)
+static_assert(SCAN_SINGLE_MAX == SCAN_SLAB, "up to here one workgroup does it all (k_scan_tiles, k_scan_hits)");
 
 // pass 1: blk_sum[block] = sum of the block's counts; bucket_count[b] += tiles of the block in order bucket b
 // (ORDER == false: the scan of the backward's record regions; the counts are record_bound(tile_count, list length))

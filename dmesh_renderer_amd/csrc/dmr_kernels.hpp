@@ -28,6 +28,18 @@ __host__ __device__ inline uint32_t hit_slot_address(uint32_t rel) {  // rel: re
     return (rel & ~(uint32_t)(HIT_BLOCK - 1)) + (rel & (uint32_t)(HIT_GROUP - 1)) * 64u + ((rel & (uint32_t)(HIT_BLOCK - 1)) / (uint32_t)HIT_GROUP);
 }
 
+// Record region of a tile: a face's records form one run padded to a multiple of HIT_GROUP, so a tile with h blended pairs
+// (counted by the forward) in a list of `len` entries needs at most h + (HIT_GROUP - 1) * min(len, h) records, rounded up to
+// whole blocks.
+__host__ __device__ inline uint32_t record_bound(uint32_t h, uint32_t len) {
+    if (h == 0u) return 0u;
+    const uint32_t b = h + (uint32_t)(HIT_GROUP - 1) * (len < h ? len : h);
+    return (b + (uint32_t)(HIT_BLOCK - 1)) & ~(uint32_t)(HIT_BLOCK - 1);
+}
+// Up to this many tiles one workgroup scans them all (k_scan_tiles, k_scan_hits), and k_tri_backward_pix can find its tile's
+// record region on its own (HitRegions below).
+constexpr int SCAN_SINGLE_MAX = 8192;
+
 // ---- per-stage HIP-event timing (dmr_api.hip); a no-op unless dmr_profile_enable() set the stage's bit
 struct StageScope {
     int stage; hipStream_t st; void* rec;
@@ -63,6 +75,7 @@ void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* 
 struct TriImageState {
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
     uint32_t* tile_hits;    // covered (pixel, face) pairs below n_contrib per tile, counted by the forward
+    uint32_t* tile_bound;   // record_bound(tile_hits, list length), written next to it (16-byte aligned, zero for empty tiles)
     const uint32_t* hit_offset;     // record regions: exclusive scan of the tiles' record bounds (k_scan_hits, backward)
     uint32_t* tile_used;            // records k_tri_backward_pix wrote into a tile's region (padded runs; <= the bound)
     const uint32_t* tile_order;  // all B * gx * gy tiles, longest list first (k_scan_tiles)
@@ -88,11 +101,19 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, const uint32_t* tile_offset, uint32_t* hit_offset, uint32_t* tile_used,
                       unsigned long long* hit_total, unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity,
                       uint32_t* overflow, hipStream_t st);
+// Without launch_scan_hits (B * tiles <= SCAN_SINGLE_MAX): every workgroup of k_tri_backward_pix sums the record bounds of
+// the tiles before its own (tile_bound: eight 16-byte loads per thread, all in flight at once) and publishes hit_offset[tile] /
+// tile_used[tile] for the hit-parallel kernel; the last tile's workgroup also leaves the total (device, pinned host) and
+// raises the overflow word when it exceeds the capacity.  One launch and ~8 us of single-workgroup latency less per step.
+struct HitRegions {
+    uint32_t* hit_offset;                 // null: the regions come from launch_scan_hits
+    unsigned long long* hit_total; unsigned long long* host_hit_total; uint32_t* overflow;  // the last two may be null
+};
 // also zeroes work[0, work_floats) (the packed accumulators)
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
-                             uint32_t capacity, float* work, size_t work_floats, hipStream_t st);
+                             uint32_t capacity, float* work, size_t work_floats, HitRegions regions, hipStream_t st);
 // one workgroup per tile (longest list first) over the tile's img.tile_used records
 void launch_tri_backward_hits(const dmr_scene& s, int gx, int gy, const float4* vproj, const uint32_t* face_list, TriImageState img,
                               const float4* pixrec, const HitRecord* hits, uint32_t capacity, float* vrow, float* frow,

@@ -95,7 +95,7 @@ struct TriParams {
     const float4* vproj; const uint32_t* tile_offset; const uint32_t* face_list;
     unsigned long long* keys;  // (depth_bits << 32 | face) of every list entry, unsorted: the forward sorts its tile's
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
-    uint32_t* tile_hits; const uint32_t* hit_offset; uint32_t* tile_used; const uint32_t* tile_order;
+    uint32_t* tile_hits; uint32_t* tile_bound; const uint32_t* hit_offset; uint32_t* tile_used; const uint32_t* tile_order;
     const unsigned long long* mask_offset;  // coverage masks: byte offset behind face_list (TriImageState)
 };
 
@@ -254,6 +254,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     // [tile-local pixel y*16+x][32-face word]: coverage bits of the chunk
     uint32_t (*const s_pm)[WORDS] = reinterpret_cast<uint32_t (*)[WORDS]>(s_mem + COV_BYTES + SHADE_BYTES);
     __shared__ uint32_t s_live[2];
+    __shared__ uint32_t s_hits[4];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
@@ -371,10 +372,18 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     }
     DMR_STAMP_RT(p, 0, 1);
 
-    if (begin != end) {  // blended (pixel, face) pairs of the tile: sizes the backward's hit-record buffer
+    {   // blended (pixel, face) pairs of the tile (sizes the backward's hit-record buffer) and the bound on its records: one
+        // workgroup per tile, so both are plain stores (empty tiles keep the zeros of k_project_verts)
 #pragma unroll
         for (int dlt = 32; dlt > 0; dlt >>= 1) n_hits += __shfl_xor(n_hits, dlt, 64);
-        if (lane == 0 && n_hits) atomicAdd(&p.tile_hits[tile], n_hits);
+        if (lane == 0) s_hits[wave] = n_hits;
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t h = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3];
+            const uint32_t bound = record_bound(h, end - begin);
+            p.tile_hits[tile] = h;
+            p.tile_bound[tile] = bound;
+        }
     }
     if (inside && !DMR_DBG(p, 128)) {
         const int64_t bpix = (int64_t)b * HW + pix_id;
@@ -468,7 +477,7 @@ constexpr uint32_t HIT_SKIPPED = 0x80000000u;
 __global__ void __launch_bounds__(256, DMR_PIX_WAVES)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity,
-                   float* __restrict__ work, uint32_t work_floats) {
+                   float* __restrict__ work, uint32_t work_floats, HitRegions regions) {
     constexpr int CHUNK = BWD_CHUNK;
     constexpr int WORDS = CHUNK / 32;
     static_assert(CHUNK == 128, "one wave scans the face counters, two per lane; 256 threads stage 128 + 128 records");
@@ -479,6 +488,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     __shared__ uint32_t s_fpad[CHUNK];              // first pad slot of the face's run | number of pad slots << 28
     __shared__ int s_ids[CHUNK][HIT_GROUP];         // face id and its three vertex ids: word q rides in record q of every group
     __shared__ uint32_t s_max_last, s_chunk_hits;
+    __shared__ unsigned long long s_before[4];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {   // every block zeroes its slice of the packed gradient accumulators kernel 2 adds into
@@ -489,18 +499,69 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
     const int tile = (int)p.tile_order[blockIdx.x];
     const int tx = tile % p.gx, ty = (tile / p.gx) % p.gy, b = tile / (p.gx * p.gy);
-    if (ty < p.r0 || ty >= p.r1) return;  // uniform
+    const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
+    // The tile's region of the record buffer.  Without a scan kernel (regions.hit_offset, dmr_kernels.hpp) it starts at the
+    // sum of the bounds of all tiles before this one -- an empty tile, or one outside this shard's band, has none -- and this
+    // workgroup publishes offset and use of its tile for the hit-parallel kernel (every tile has exactly one workgroup here).
+    uint32_t region0 = 0u;
+    unsigned long long before = 0ull;  // (this thread's part of) the bounds of the tiles before this one
+    const bool self = regions.hit_offset != nullptr, last = tile == p.B * p.gx * p.gy - 1;
+    uint32_t my_bound = 0u;
+    if (self) {
+        static_assert(SCAN_SINGLE_MAX == 8 * 256 * 4, "eight 16-byte loads per thread cover every tile");
+        const uint32_t bound = my_bound = p.tile_bound[tile];
+        if (bound == 0u && !last) {  // uniform
+            if (tid == 0) p.tile_used[tile] = 0u;
+            return;
+        }
+    } else {
+        if (ty < p.r0 || ty >= p.r1) return;  // uniform
+        if (begin == end) return;  // uniform
+        region0 = p.hit_offset[tile];
+        if (region0 == p.hit_offset[tile + 1]) return;  // no pixel of the tile blended anything
+    }
+    if (self) {
+        const uint32_t bound = my_bound;
+        // this thread's part of the bounds of the tiles before this one: eight 16-byte loads, all in flight at once.
+        // (Measured at C4, k_tri_backward_pix / step: this form 90 us / 0.320 ms; the same loads consumed behind the pixel's
+        // own loads, 32 registers live across the ray set-up, or the pixel's loads requested first: spills at the kernel's
+        // 80-register cap, 95-100 us / 0.33; block sums added by the forward with
+        // atomics so that two loads per thread suffice: 85 us but k_tri_forward + 3 us at C4, + 9 us at C2; 96 dword loads of
+        // tile_hits / tile_offset: 93 us; the scan kernel this replaces: 85 us + 8 us + a launch, 0.331 ms.)
+        const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(p.tile_bound);
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int q = 256 * j + tid;
+            v[j] = 4 * q < tile ? tb[q] : make_uint4(0u, 0u, 0u, 0u);  // (a last partial quad reads into the next array of the buffer)
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = 4 * (256 * j + tid);
+            before += (unsigned long long)((i < tile ? v[j].x : 0u)) + (i + 1 < tile ? v[j].y : 0u);
+            before += (unsigned long long)((i + 2 < tile ? v[j].z : 0u)) + (i + 3 < tile ? v[j].w : 0u);
+        }
+        if (bound == 0u) {  // the last tile, and nothing blended in it: only the total is wanted of this workgroup
+#pragma unroll
+            for (int dlt = 32; dlt > 0; dlt >>= 1) before += __shfl_xor(before, dlt, 64);
+            if (lane == 0) s_before[wave] = before;
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long total = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+                *regions.hit_total = total;
+                if (regions.host_hit_total) *regions.host_hit_total = total;
+                if (regions.overflow && total > (unsigned long long)capacity) *regions.overflow = 1u;
+                p.tile_used[tile] = 0u;
+            }
+            return;
+        }
+    }
     const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
     const int px = tx * TILE + lx, py = ty * TILE + ly;
     const bool inside = px < p.W && py < p.H;
     const int64_t HW = (int64_t)p.H * p.W;
     const int64_t pix_id = (int64_t)p.W * py + px;
     const int64_t bpix = (int64_t)b * HW + pix_id;
-
-    const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
-    if (begin == end) return;  // uniform
-    uint32_t hit_cursor = p.hit_offset[tile];  // the tile's region of the record buffer
-    if (hit_cursor == p.hit_offset[tile + 1]) return;  // no pixel of the tile blended anything
 
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
@@ -530,9 +591,29 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     if (tid < CHUNK) s_fcnt[tid] = 0u;
     __syncthreads();
     if (last_contributor) atomicMax(&s_max_last, last_contributor);
+    if (self) {
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) before += __shfl_xor(before, dlt, 64);
+        if (lane == 0) s_before[wave] = before;
+    }
     __syncthreads();
     const uint32_t total = s_max_last;  // list positions >= total contribute to no pixel of the tile
+    if (self) {
+        before = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+        region0 = (uint32_t)before;  // (offsets beyond 2^32 wrap harmlessly: the total says so)
+        if (tid == 0) {
+            regions.hit_offset[tile] = region0;
+            if (last) {
+                const unsigned long long all = before + p.tile_bound[tile];
+                *regions.hit_total = all;
+                if (regions.host_hit_total) *regions.host_hit_total = all;
+                if (regions.overflow && all > (unsigned long long)capacity) *regions.overflow = 1u;
+            }
+            if (total == 0) p.tile_used[tile] = 0u;  // (cannot happen for a tile with blended pairs; published all the same)
+        }
+    }
     if (total == 0) return;
+    uint32_t hit_cursor = region0;  // the tile's region of the record buffer
 
     // pixel-thread state of the reverse walk
     float T = prev_T_final;
@@ -540,7 +621,6 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     float acr0 = 0, acr1 = 0, acr2 = 0, acrd = 0;
     float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_depth = 0;
     const uint32_t pixel = (uint32_t)pl;  // records carry the tile-local pixel
-    const uint32_t region0 = p.hit_offset[tile];
 
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
     // Chunks are the forward's (list positions [c * CHUNK, (c + 1) * CHUNK), cut at `total`), walked from the back;
@@ -1100,7 +1180,7 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list; p.keys = nullptr;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
-    p.tile_hits = img.tile_hits; p.hit_offset = img.hit_offset; p.tile_used = img.tile_used; p.tile_order = img.tile_order;
+    p.tile_hits = img.tile_hits; p.tile_bound = img.tile_bound; p.hit_offset = img.hit_offset; p.tile_used = img.tile_used; p.tile_order = img.tile_order;
     p.mask_offset = img.mask_offset;
     p.list_capacity = 0xffffffffu;
     return p;
@@ -1120,12 +1200,12 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                              const uint32_t* tile_offset, const uint32_t* face_list, TriImageState img,
                              const float* dL_dcolor, const float* dL_ddepth, float4* pixrec, HitRecord* hits,
-                             uint32_t capacity, float* work, size_t work_floats, hipStream_t st) {
-    if (r1 <= r0) return;
+                             uint32_t capacity, float* work, size_t work_floats, HitRegions regions, hipStream_t st) {
+    if (r1 <= r0 && !regions.hit_offset) return;
     TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
     k_tri_backward_pix<<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity,
-                                                                            work, (uint32_t)work_floats);
+                                                                            work, (uint32_t)work_floats, regions);
 }
 
 void launch_tri_backward_hits(const dmr_scene& s, int gx, int gy, const float4* vproj, const uint32_t* face_list, TriImageState img,
