@@ -16,7 +16,8 @@ out = sys.argv[1]
 res = {}
 for f in sorted(glob.glob(f"{out}/kernel_stats_rank_*.csv")):
     tag = f.split("rank_")[1][:-4]
-    rows = [r for r in csv.DictReader(open(f)) if "dmr::" in r["Name"]]
+    # (kernels of the steady state only: k_scan_hits runs once, in the first backward, which has no size estimate yet)
+    rows = [r for r in csv.DictReader(open(f)) if "dmr::" in r["Name"] and int(r["Calls"]) >= 10]
     per = {r["Name"].split("(")[0].replace("void ", "").replace("dmr::", "").split("<")[0]: round(float(r["AverageNs"]) / 1000, 1) for r in rows}
     b = json.load(open(f"{out}/bench_{tag}.json"))
     res[tag] = {"kernel_sum_us": round(sum(per.values()), 1), "ms_per_step": b["ms_per_step"], "band": b["config"]["parallelism"], "kernels_us": per}
