@@ -220,6 +220,43 @@ def test_size_guess_refuted_by_screen_filling_faces(oracle, hip_device):
     assert rs[1] > 2.0 * rs[0], "the second scene must refute the size guess by a wide margin"
 
 
+@pytest.mark.parametrize("scale,rows", [(4.0, (0, 0)), (0.45, (0, 0)), (4.0, (9, 41))])
+def test_record_regions_without_a_scan_launch(oracle, hip_device, scale, rows):
+    """A frame of exactly 8 192 tiles (2048 x 1024), the most k_tri_backward_pix lays the record regions out for by itself
+    (dmr_kernels.hpp, HitRegions).  The first backward of a view configuration has no size estimate and goes through
+    k_scan_hits; every later one sums the forward's per-tile record bounds inside the per-pixel kernel, the last tile's
+    workgroup leaves the total -- with the last tile busy (scale 4: the mesh covers the frame), empty (scale 0.45: only its
+    total is wanted of that workgroup) and outside the rendered band of tile rows.  Both must give the oracle's gradients."""
+    from dmesh_renderer_amd import _C
+    L, n, B, H, W = 3, 40, 1, 1024, 2048
+    assert ((H + 15) // 16) * ((W + 15) // 16) * B == 8192
+    d = scenes.layered_sheets(L, n, B, H, W, seed=5, opacity=(0.1, 0.5))
+    d["verts"] = d["verts"] * th.tensor([scale, scale, 1.0])
+    sc = oracle.scene_from_module_inputs(d, H, W, rows=rows)
+    ocolor, odepth, ost = oracle.tri_forward(sc)
+    gc, gd = upstream_grads(B, H, W)
+    og = oracle.tri_backward(sc, ost, gc.numpy(), gd.numpy())
+    args = c_args(d, hip_device)
+    last_tile_busy = None
+    for call in range(3):  # scan kernel, then twice the per-pixel kernel's own layout (default call, asynchronous call)
+        _C.set_async(call == 2)
+        try:
+            out = _C.render_tris(*args, H, W, rows=rows)
+            g = _C.render_tris_backward(*args, gc.to(hip_device), gd.to(hip_device), out[0], *out[3:7], rows=rows)
+            th.cuda.synchronize()
+        finally:
+            _C.set_async(False)
+        assert not _C.overflowed()
+        if call < 2:
+            assert out[0] == ost.num_rendered
+        hits = _C.export("tile_hits", args, False, out[0], out[3:7], H, W, th.int32).cpu().numpy()
+        last_tile_busy = bool(hits[-1] > 0)
+        assert np.abs(out[1].cpu().numpy() - ocolor).max() <= FWD_TOL
+        for got, key in zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")):
+            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (call, key)
+    assert last_tile_busy == (scale > 1.0 and rows == (0, 0))
+
+
 def test_module_autograd(oracle, hip_device):
     """TriRenderer Module: loss.backward() routes the five gradients like the reference wrapper."""
     import dmesh_renderer_amd as dmr
