@@ -813,7 +813,7 @@ __device__ __forceinline__ F3 load3(const float* __restrict__ a, int id) { retur
 }  // namespace fm
 
 #ifndef DMR_VTAB
-#define DMR_VTAB 512
+#define DMR_VTAB 640
 #endif
 #ifndef DMR_HITS_UNROLL
 #define DMR_HITS_UNROLL 1
@@ -822,7 +822,9 @@ constexpr int VTAB = DMR_VTAB;   // vertex-row slots per workgroup
 constexpr int TAB_PROBES = 16;
 constexpr uint32_t TAB_EMPTY = 0xffffffffu;
 
-// Workgroup-level aggregation of the vertex gradient rows (LDS, 37 KB).
+// Workgroup-level aggregation of the vertex gradient rows (LDS: 640 slots, 38 KB; with the tile's pixel records 46 KB: three
+// workgroups per CU.  C4's busiest tiles touch ~500 rows: 512 slots left them with probe sequences at load factor ~1 --
+// k_tri_backward_hits 101.4 us with 512 slots, 95.6-98.2 with 576 / 640 / 704, 117 with 768 = two workgroups per CU).
 // Global float atomics execute at the memory side at ~20 G 64-byte requests/s chip-wide whatever they carry
 // (MI355X_MICROARCH.md, "Global float atomics"): with one request per (segment, row) -- 3 vertex rows + 1 face row
 // per list entry -- this kernel was bound by exactly that (0.195 ms with the atomics, 0.110 ms without, 0.195 ms
@@ -1120,7 +1122,7 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
     DMR_STAMP(p, 2, 0u, 6);
     if (DMR_DBG(p, 1024)) return;
     // (eight slots per lane are read before the first atomic goes out: the LDS latencies overlap instead of adding up)
-    constexpr int FLUSH_BATCH = VTAB % 256 == 0 ? 8 : 4;
+    constexpr int FLUSH_BATCH = VTAB % 256 == 0 ? 8 : (VTAB % 128 == 0 ? 4 : 2);
     static_assert(VTAB % (32 * FLUSH_BATCH) == 0, "table size");
     const int comp = tid & 7;
     for (int s0 = 0; s0 < VTAB; s0 += 32 * FLUSH_BATCH) {
