@@ -474,6 +474,11 @@ __device__ __forceinline__ void seg_scan_level(int k, float (&g)[NSCAN]) {
 // tests/tools/fuzz_campaign.py: a sliver face whose denom is 0 at some pixels only).
 constexpr uint32_t HIT_SKIPPED = 0x80000000u;
 
+// SCANNED: the record regions come from k_scan_hits (frames above SCAN_SINGLE_MAX tiles, first call); else they are laid out
+// here (HitRegions, dmr_kernels.hpp) -- tested at run time in that instantiation: with the test folded away the register
+// allocator spills 16 bytes at the kernel's 80-register cap (k_tri_backward_pix 89 -> 91-93 us at C4), as it is it does not;
+// the scanned instantiation without the other path's code is 3 % faster at C5 (2.66 -> 2.58 ms).
+template <bool SCANNED>
 __global__ void __launch_bounds__(256, DMR_PIX_WAVES)
 k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    float4* __restrict__ pixrec, HitRecord* __restrict__ hits, uint32_t capacity,
@@ -505,7 +510,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
     // workgroup publishes offset and use of its tile for the hit-parallel kernel (every tile has exactly one workgroup here).
     uint32_t region0 = 0u;
     unsigned long long before = 0ull;  // (this thread's part of) the bounds of the tiles before this one
-    const bool self = regions.hit_offset != nullptr, last = tile == p.B * p.gx * p.gy - 1;
+    const bool self = !SCANNED && regions.hit_offset != nullptr, last = tile == p.B * p.gx * p.gy - 1;
     uint32_t my_bound = 0u;
     if (self) {
         static_assert(SCAN_SINGLE_MAX == 8 * 256 * 4, "eight 16-byte loads per thread cover every tile");
@@ -1206,8 +1211,11 @@ void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1,
     if (r1 <= r0 && !regions.hit_offset) return;
     TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
-    k_tri_backward_pix<<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity,
-                                                                            work, (uint32_t)work_floats, regions);
+    const dim3 grid((unsigned)(s.B * gx * gy)), block(256);
+    if (regions.hit_offset)
+        k_tri_backward_pix<false><<<grid, block, 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity, work, (uint32_t)work_floats, regions);
+    else
+        k_tri_backward_pix<true><<<grid, block, 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity, work, (uint32_t)work_floats, regions);
 }
 
 void launch_tri_backward_hits(const dmr_scene& s, int gx, int gy, const float4* vproj, const uint32_t* face_list, TriImageState img,
