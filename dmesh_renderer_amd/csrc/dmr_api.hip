@@ -241,8 +241,9 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (capacity > 0) {
             dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
                                       (uint32_t)capacity, tet ? nullptr : is.mask_offset, bs.mask_offset, st);
-            // (the tri forward sorts every tile's list at the start of that tile's workgroup)
-            if (tet) dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, bs.capacity, st);
+            // (up to SCAN_SINGLE_MAX tiles the tri forward sorts every tile's list at the start of that tile's workgroup)
+            if (tet || d.ntiles > dmr::SCAN_SINGLE_MAX)
+                dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, bs.capacity, st);
         }
         render(bs);
         return 0;
@@ -383,7 +384,8 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     auto render = [&](const BinningState& bs) {
         dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.tile_bound, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
         const dmr_scene sc = canonical(s, is.mats);
-        dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.keys, bs.face_list, bs.capacity, img, out_color,
+        dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, d.ntiles > dmr::SCAN_SINGLE_MAX ? nullptr : bs.keys,
+                                bs.face_list, bs.capacity, img, out_color,
                                 out_depth, st);
     };
     return run_forward(s, false, d, alloc, ctx, st, ps, fs, is, num_rendered, render);

@@ -67,7 +67,7 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
                           unsigned long long* mask_offset_dst, unsigned long long mask_offset, hipStream_t st);
 // capacity: entries the binning buffer holds; it is below R only while a size guess is being refuted (dmr_api.hip):
 // every kernel that walks the tile lists clamps to it, the results are then thrown away and redone.
-// (tet path only: the tri forward sorts its tiles itself)
+// (tet path, and tri frames above SCAN_SINGLE_MAX tiles: otherwise the tri forward sorts its tiles itself)
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
                        uint32_t* face_list, uint32_t capacity, hipStream_t st);
 
@@ -90,8 +90,8 @@ inline size_t mask_slots(size_t list_capacity, size_t ntiles) { return list_capa
 // consumed one per lane by k_tri_backward_hits.
 // (A 32-byte record carrying face and vertex ids was tried: kernel 2 did not get faster, kernel 1 got 9 % slower.)
 struct alignas(16) HitRecord { uint32_t id; uint32_t pixel; float T; float dL_dalpha; };  // id: word (slot mod HIT_GROUP) of {face, v0, v1, v2}; pixel: tile-local
-// keys: the unsorted (depth_bits << 32 | face) list entries of the scatter pass; every tile's workgroup sorts its own list
-// (dmr_sort.hpp) into face_list before compositing it -- no launch_sort_tiles on the tri path
+// keys: the unsorted (depth_bits << 32 | face) list entries of the scatter pass: every tile's workgroup sorts its own list
+// (dmr_sort.hpp) into face_list before compositing it, no launch_sort_tiles; null: face_list is sorted already
 void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
                         const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list, uint32_t capacity, TriImageState img,
                         float* out_color, float* out_depth, hipStream_t st);

@@ -241,7 +241,9 @@ __device__ __forceinline__ void rasterize_faces(const CovRec* __restrict__ cov, 
 // idle chip (an eighth of the tiles took 19 us, profiles/r02/shard_kernel_sums_c4.json); here that chain runs beside the
 // other workgroups' compositing.  The sorted ids go to face_list for this kernel's own staging (a block's global writes
 // are visible to it behind a barrier) and for the backward.
-template <int CHUNK>
+// (SORT == false: the lists were sorted by k_sort_tiles.  Frames of many tiles keep the chip busy in either kernel and the
+// separate sort is the cheaper one there -- C5, 262 144 tiles: 0.39 + 2.01 ms against 2.48 ms fused; dmr_api.hip decides.)
+template <int CHUNK, bool SORT>
 __global__ void __launch_bounds__(256, DMR_FWD_WAVES)
 k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ out_depth) {
     constexpr int WORDS = CHUNK / 32;
@@ -283,9 +285,11 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         return;  // uniform
     }
 
-    sort_tile(begin, end - begin, reinterpret_cast<uint64_t*>(p.keys), const_cast<uint32_t*>(p.face_list),
-              reinterpret_cast<uint64_t*>(s_mem), reinterpret_cast<uint32_t*>(s_mem + SORT_LDS_KEYS * sizeof(uint64_t)), (uint32_t)tid);
-    __syncthreads();  // face_list[begin, end) is sorted and visible to this workgroup; the LDS is free
+    if (SORT) {
+        sort_tile(begin, end - begin, reinterpret_cast<uint64_t*>(p.keys), const_cast<uint32_t*>(p.face_list),
+                  reinterpret_cast<uint64_t*>(s_mem), reinterpret_cast<uint32_t*>(s_mem + SORT_LDS_KEYS * sizeof(uint64_t)), (uint32_t)tid);
+        __syncthreads();  // face_list[begin, end) is sorted and visible to this workgroup; the LDS is free
+    }
 
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside && !DMR_DBG(p, 32)) pixel_ray<false>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd);
@@ -1201,7 +1205,9 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
     p.keys = reinterpret_cast<unsigned long long*>(keys);
     p.list_capacity = capacity;
     StageScope t(DMR_STAGE_TRI_FORWARD, st);
-    k_tri_forward<FWD_CHUNK><<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, out_color, out_depth);
+    const dim3 grid((unsigned)(s.B * gx * gy)), block(256);
+    if (keys) k_tri_forward<FWD_CHUNK, true><<<grid, block, 0, st>>>(p, out_color, out_depth);
+    else k_tri_forward<FWD_CHUNK, false><<<grid, block, 0, st>>>(p, out_color, out_depth);
 }
 
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,
