@@ -241,8 +241,8 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (capacity > 0) {
             dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
                                       (uint32_t)capacity, tet ? nullptr : is.mask_offset, bs.mask_offset, st);
-            // (up to SCAN_SINGLE_MAX tiles the tri forward sorts every tile's list at the start of that tile's workgroup)
-            if (tet || d.ntiles > dmr::SCAN_SINGLE_MAX)
+            // (up to SCAN_SINGLE_MAX tiles the tri forward / the tet first-hit kernel sort a tile's list at the start of its workgroup)
+            if (d.ntiles > dmr::SCAN_SINGLE_MAX)
                 dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, bs.capacity, st);
         }
         render(bs);
@@ -520,7 +520,7 @@ int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, floa
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tet_prep(sc, img, st);
         dmr::launch_tet_first_intersect(sc, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
-                                        bs.face_list, bs.capacity, img, st);
+                                        d.ntiles > dmr::SCAN_SINGLE_MAX ? nullptr : bs.keys, bs.face_list, bs.capacity, img, st);
         dmr::launch_tet_forward(sc, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
     };
     return run_forward(s, true, d, alloc, ctx, st, ps, fs, is, num_rendered, render);

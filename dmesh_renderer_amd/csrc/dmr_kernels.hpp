@@ -67,7 +67,7 @@ void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_
                           unsigned long long* mask_offset_dst, unsigned long long mask_offset, hipStream_t st);
 // capacity: entries the binning buffer holds; it is below R only while a size guess is being refuted (dmr_api.hip):
 // every kernel that walks the tile lists clamps to it, the results are then thrown away and redone.
-// (tet path, and tri frames above SCAN_SINGLE_MAX tiles: otherwise the tri forward sorts its tiles itself)
+// (frames above SCAN_SINGLE_MAX tiles: below, the tri forward / the tet first-hit kernel sort their tiles themselves)
 void launch_sort_tiles(int ntiles, const uint32_t* tile_offset, const uint32_t* tile_order, uint64_t* keys,
                        uint32_t* face_list, uint32_t capacity, hipStream_t st);
 
@@ -133,8 +133,9 @@ size_t tet_facerec_bytes();
 size_t tet_colrec_bytes();
 // builds the packed march records from the scene (every forward call)
 void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st);
+// keys: as launch_tri_forward (non-null: every tile's workgroup sorts its list itself)
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
-                                const float* max_depth, const uint32_t* tile_offset, const uint32_t* face_list,
+                                const float* max_depth, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list,
                                 uint32_t capacity, TetImageState img, hipStream_t st);
 void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
                         float* out_color, float* out_depth, float* out_active, hipStream_t st);

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "dmr_kernels.hpp"
+#include "dmr_sort.hpp"
 
 namespace dmr {
 
@@ -122,10 +123,16 @@ __device__ __forceinline__ float oriented_dot(const TetFaceRec& r, bool flip, V3
     return flip ? -v : v;
 }
 
+// SORT: the workgroup first sorts its tile's list (dmr_sort.hpp; keys = the scatter pass's unsorted entries), as the tri
+// forward does: the sort kernel of its own was the serial chain of the longest tile on a nearly idle chip.
+template <bool SORT>
 __global__ void __launch_bounds__(256)
 k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const float* __restrict__ max_depth,
-                      const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ face_list, uint32_t capacity) {
-    __shared__ HitRec s_rec[FI_CHUNK];
+                      const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ face_list, uint64_t* __restrict__ keys,
+                      uint32_t capacity) {
+    constexpr int REC_BYTES = FI_CHUNK * (int)sizeof(HitRec);
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[SORT && SORT_LDS_BYTES > REC_BYTES ? SORT_LDS_BYTES : REC_BYTES];
+    HitRec* const s_rec = reinterpret_cast<HitRec*>(s_mem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
     const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
@@ -141,6 +148,11 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
     // valid face ids: the tile is treated as empty)
     uint32_t begin = tile_offset[tile], end = tile_offset[tile + 1];
     if (end > capacity) begin = end = 0u;
+    if (SORT && begin != end) {  // uniform
+        sort_tile(begin, end - begin, keys, face_list, reinterpret_cast<uint64_t*>(s_mem),
+                  reinterpret_cast<uint32_t*>(s_mem + SORT_LDS_KEYS * sizeof(uint64_t)), (uint32_t)tid);
+        __syncthreads();  // face_list[begin, end) is sorted and visible to this workgroup; the LDS is free
+    }
 
     bool done = !inside;
     float min_T = -1.0f, min_T_max_depth = -1.0f;
@@ -545,12 +557,14 @@ void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st) {
 }
 
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
-                                const float* max_depth, const uint32_t* tile_offset, const uint32_t* face_list,
+                                const float* max_depth, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list,
                                 uint32_t capacity, TetImageState img, hipStream_t st) {
     if (r1 <= r0) return;
     TetParams p = make_params(s, gx, gy, r0, img);
     StageScope t(DMR_STAGE_TET_FIRST, st);
-    k_tet_first_intersect<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, key_depth, max_depth, tile_offset, face_list, capacity);
+    const dim3 grid(gx, r1 - r0, s.B), block(256);
+    if (keys) k_tet_first_intersect<true><<<grid, block, 0, st>>>(p, key_depth, max_depth, tile_offset, face_list, keys, capacity);
+    else k_tet_first_intersect<false><<<grid, block, 0, st>>>(p, key_depth, max_depth, tile_offset, face_list, nullptr, capacity);
 }
 
 void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
