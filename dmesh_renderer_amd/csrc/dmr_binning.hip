@@ -10,7 +10,8 @@
 // ONE global 64-bit radix sort over all R pairs (k = ceil((32+bit)/8) passes, ~24 B per
 // pair per pass).  Here the tile is known at emission time, so pairs are counted and
 // scattered straight into their tile's segment (counting sort on the tile digit) and
-// each segment is then sorted by (depth_bits, face_id) inside LDS by one workgroup.
+// each segment is then sorted by (depth_bits, face_id) inside LDS by one workgroup
+// (dmr_sort.hpp: the consumer's workgroup of that tile up to 8 192 tiles, k_sort_tiles above).
 // Within a (view, tile) a face occurs at most once, so (depth_bits, face_id) is a total
 // order and equals the order of the reference's STABLE sort, whose ties keep emission
 // order = ascending face id (Q6).  The result -- per-tile face lists and ranges -- is

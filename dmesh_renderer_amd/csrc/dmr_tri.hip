@@ -19,10 +19,11 @@
 //      for ds_read_b128).
 //
 // The pixel's result is the same sequence of blends as the reference's loop.  Rays are recomputed per pixel (not
-// stored).  The backward is two kernels: k_tri_backward_pix (same layout, chunks from the back: the per-pixel
-// sequential part, one 16-byte record per blended pair, face-major) and k_tri_backward_hits (one lane per record:
-// the 23 gradient components, segmented DPP scan, workgroup LDS tables, packed atomics).  DESIGN.md section 5 has the
-// measurements behind every step.
+// stored).  Up to 8 192 tiles the forward's workgroup first sorts its tile's list (dmr_sort.hpp).  The backward is two
+// kernels: k_tri_backward_pix (same layout, chunks from the back: the per-pixel sequential part, one 16-byte record per
+// blended pair, face-major; it also lays out the tiles' record regions) and k_tri_backward_hits (one lane per group of
+// four records of a list entry: 21 sums -- the vertex-position gradient as ray moments --, segmented DPP scan, workgroup
+// LDS table, packed atomics).  DESIGN.md section 5 has the measurements behind every step.
 #include <algorithm>
 #include <cstdlib>
 
