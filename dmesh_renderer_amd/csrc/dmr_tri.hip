@@ -864,19 +864,49 @@ struct HitsLds {
 // instruction -- sends both out in one memory-side request whenever a tile holds both (neighbouring vertex ids are
 // neighbouring vertices in most meshes; nothing is lost when they are not): 106.6 -> 102.6 us at C4.
 template <int SLOTS>
-__device__ __forceinline__ int tab_find(uint32_t* __restrict__ key, uint32_t rid) {
+__device__ __forceinline__ uint32_t tab_home(uint32_t rid) {  // the slot pair a row hashes to
     constexpr int PAIRS = SLOTS / 2;
     constexpr bool POW2 = (PAIRS & (PAIRS - 1)) == 0;
     static_assert(SLOTS % 2 == 0, "pairs of slots");
     const uint32_t h = (rid >> 1) * 2654435761u;
-    uint32_t pair = POW2 ? ((h >> 8) & (uint32_t)(PAIRS - 1)) : __umulhi(h, (uint32_t)PAIRS);
-    for (int i = 0; i < TAB_PROBES; i++) {
+    return POW2 ? ((h >> 8) & (uint32_t)(PAIRS - 1)) : __umulhi(h, (uint32_t)PAIRS);
+}
+// probes `probes` slot pairs from `pair` on; -1: no slot (the row goes out with direct atomics)
+template <int SLOTS>
+__device__ __forceinline__ int tab_probe(uint32_t* __restrict__ key, uint32_t rid, uint32_t pair, int probes) {
+    constexpr int PAIRS = SLOTS / 2;
+    constexpr bool POW2 = (PAIRS & (PAIRS - 1)) == 0;
+    for (int i = 0; i < probes; i++) {
         const uint32_t slot = 2u * pair + (rid & 1u);
         const uint32_t prev = atomicCAS(&key[slot], TAB_EMPTY, rid);
         if (prev == TAB_EMPTY || prev == rid) return (int)slot;
         pair = POW2 ? ((pair + 1u) & (uint32_t)(PAIRS - 1)) : (pair + 1u == (uint32_t)PAIRS ? 0u : pair + 1u);
     }
     return -1;
+}
+template <int SLOTS>
+__device__ __forceinline__ int tab_find(uint32_t* __restrict__ key, uint32_t rid) {
+    return tab_probe<SLOTS>(key, rid, tab_home<SLOTS>(rid), TAB_PROBES);
+}
+// The three rows of a list entry: their first probes are in flight together (three LDS round trips one after the other
+// were a sizeable part of what a segment tail costs); only a row whose home slot is taken by another row probes on.
+template <int SLOTS>
+__device__ __forceinline__ void tab_find3(uint32_t* __restrict__ key, const uint32_t (&rid)[3], int (&slot)[3]) {
+    constexpr int PAIRS = SLOTS / 2;
+    constexpr bool POW2 = (PAIRS & (PAIRS - 1)) == 0;
+    uint32_t home[3], prev[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++) home[w] = tab_home<SLOTS>(rid[w]);
+#pragma unroll
+    for (int w = 0; w < 3; w++) prev[w] = atomicCAS(&key[2u * home[w] + (rid[w] & 1u)], TAB_EMPTY, rid[w]);
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        if (prev[w] == TAB_EMPTY || prev[w] == rid[w]) slot[w] = (int)(2u * home[w] + (rid[w] & 1u));
+        else {
+            const uint32_t next = POW2 ? ((home[w] + 1u) & (uint32_t)(PAIRS - 1)) : (home[w] + 1u == (uint32_t)PAIRS ? 0u : home[w] + 1u);
+            slot[w] = tab_probe<SLOTS>(key, rid[w], next, TAB_PROBES - 1);
+        }
+    }
 }
 
 // One workgroup per tile (longest list first), one lane per GROUP of HIT_GROUP consecutive records -- all of one list
@@ -1107,22 +1137,24 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             const float rows[3][7] = {{dp0.x, dp0.y, dp0.z, g[7], g[8], g[9], g[16]},
                                       {dp1.x, dp1.y, dp1.z, g[10], g[11], g[12], g[17]},
                                       {dp2.x, dp2.y, dp2.z, g[13], g[14], g[15], g[18]}};
-            const int vid[3] = {v0, v1, v2};
-#pragma unroll
-            for (int w = 0; w < 3; w++) {
-                const uint32_t rid = (uint32_t)b * (uint32_t)p.P + (uint32_t)vid[w];
-                // (ablation build, DMR_ABLATE bit 2048, tests only: odd rows are refused a slot, which exercises the direct-atomic fallback)
-                const int slot = (DMR_DBG(p, 2048) && (rid & 1u)) ? -1 : tab_find<VTAB>(L.vkey, rid);
-                if (slot >= 0) {
-#pragma unroll
-                    for (int c = 0; c < 7; c++) atomicAdd(&L.vval[slot][c], (double)rows[w][c]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 7; c++) atomicAdd(&vrow[(int64_t)rid * VROW + c], rows[w][c]);
-                }
-            }
             const int64_t fid = (int64_t)b * p.F + face;
             atomicAdd(&frow[fid * FROW], g[19]); atomicAdd(&frow[fid * FROW + 1], g[20]);
+            const uint32_t rid[3] = {(uint32_t)b * (uint32_t)p.P + (uint32_t)v0, (uint32_t)b * (uint32_t)p.P + (uint32_t)v1,
+                                     (uint32_t)b * (uint32_t)p.P + (uint32_t)v2};
+            int slot[3];
+            tab_find3<VTAB>(L.vkey, rid, slot);
+#pragma unroll
+            for (int w = 0; w < 3; w++) {
+                // (ablation build, DMR_ABLATE bit 2048, tests only: odd rows are refused their slot, which exercises the direct-atomic fallback)
+                if (DMR_DBG(p, 2048) && (rid[w] & 1u)) slot[w] = -1;
+                if (slot[w] >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 7; c++) atomicAdd(&L.vval[slot[w]][c], (double)rows[w][c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 7; c++) atomicAdd(&vrow[(int64_t)rid[w] * VROW + c], rows[w][c]);
+                }
+            }
         }
         DMR_STAMP(p, 2, g0 / 256u, 4);
     }
