@@ -857,7 +857,14 @@ struct HitsLds {
 #endif
     uint32_t vkey[VTAB];
     double vval[VTAB][7];   // dx dy dz dr dg db ddepth of row (view, vertex)
+    uint32_t frow_stage[4][64][3];  // per wave: {face row id, dopacity, dintense} of the round's segment tails (see the loop)
 };
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Rows 2k and 2k + 1 share a 64-byte line of `vrow`; they hash to the two slots of one PAIR of slots (the probe sequence
 // moves pair by pair and keeps the row's parity), so the flush -- consecutive slots in consecutive lane groups of one
@@ -1132,13 +1139,33 @@ k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRec
             const F3 dT = cross(mA, fE2) + g[6] * fE12;
             dp0 = -(dp1 + dp2 + dT);
         }
-        // a tail lane adds its entry's three vertex rows into the table and sends the face row out, from its registers
+        // The face rows (opacity, intensity: two adjacent floats) of the round's tails go out first.  A tail lane sending its two
+        // values itself is two memory-side requests (two instructions): 4.6 us of this kernel at C4.  So the tails are compacted
+        // through 12 bytes of wave-private LDS each and lanes 2r / 2r + 1 send the two floats of tail r in ONE instruction -- one
+        // 8-byte request per tail (up to 32 tails per instruction).
+        {
+            const bool ft = tail && !DMR_DBG(p, 512);
+            const uint64_t tmask = __ballot(ft);
+            const int ntail = __popcll(tmask);
+            if (ft) {
+                uint32_t* st = L.frow_stage[tid >> 6][__popcll(tmask & ((1ull << lane) - 1ull))];
+                st[0] = (uint32_t)b * (uint32_t)p.F + (uint32_t)face; st[1] = __float_as_uint(g[19]); st[2] = __float_as_uint(g[20]);
+            }
+            wave_lds_sync();
+            for (int t0 = 0; t0 < ntail; t0 += 32) {
+                const int t = t0 + (lane >> 1);
+                if (t < ntail) {
+                    const uint32_t* st = L.frow_stage[tid >> 6][t];
+                    atomicAdd(&frow[(int64_t)st[0] * FROW + (lane & 1)], __uint_as_float(st[1 + (lane & 1)]));
+                }
+            }
+            wave_lds_sync();  // (the stage may be refilled by the next round)
+        }
+        // a tail lane adds its entry's three vertex rows into the table, from its registers
         if (tail && !DMR_DBG(p, 512)) {
             const float rows[3][7] = {{dp0.x, dp0.y, dp0.z, g[7], g[8], g[9], g[16]},
                                       {dp1.x, dp1.y, dp1.z, g[10], g[11], g[12], g[17]},
                                       {dp2.x, dp2.y, dp2.z, g[13], g[14], g[15], g[18]}};
-            const int64_t fid = (int64_t)b * p.F + face;
-            atomicAdd(&frow[fid * FROW], g[19]); atomicAdd(&frow[fid * FROW + 1], g[20]);
             const uint32_t rid[3] = {(uint32_t)b * (uint32_t)p.P + (uint32_t)v0, (uint32_t)b * (uint32_t)p.P + (uint32_t)v1,
                                      (uint32_t)b * (uint32_t)p.P + (uint32_t)v2};
             int slot[3];
