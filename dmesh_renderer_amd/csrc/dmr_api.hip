@@ -55,8 +55,12 @@ struct ImageState {
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
     int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
     unsigned long long* mask_offset;  // tri: byte offset of the coverage masks inside the binning buffer (written on the device)
+    dmr::TetSeq* seq;  // tet: the march sequence's descriptor (dmr_kernels.hpp)
 };
-struct BinningState { uint64_t* keys; uint32_t* face_list; uint32_t capacity; unsigned long long mask_offset; };
+struct BinningState {
+    uint64_t* keys; uint32_t* face_list; uint32_t capacity; unsigned long long mask_offset;
+    char* base; unsigned long long seq_offset; uint32_t seq_steps;  // tet: the march sequence's region
+};
 
 size_t carve_point(void* b, size_t BP, PointState& s) { Carver c(b); s.vproj = c.take<float4>(BP); return c.off; }
 size_t carve_face(void* b, size_t BF, size_t F, size_t T, bool tet, FaceState& s) {
@@ -89,8 +93,10 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
         s.first_face = c.take<int32_t>(npix); s.first_tet = c.take<int32_t>(npix);
         s.last_face = c.take<int32_t>(npix); s.last_tet = c.take<int32_t>(npix);
         s.is_active = c.take<uint8_t>(npix);
+        s.seq = c.take<dmr::TetSeq>(1);
     } else {
         s.first_face = s.first_tet = s.last_face = s.last_tet = nullptr; s.is_active = nullptr;
+        s.seq = nullptr;
     }
     return c.off;
 }
@@ -99,12 +105,16 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
 // ... then, tri only, the coverage masks the forward leaves for the backward (dmr_kernels.hpp): their place depends on the
 // capacity, so the kernels take it from the device (ImageState::mask_offset, written by the scatter pass).  mask_tiles = 0:
 // no masks (tet; the backward, which never carves beyond the lists on the host).
-size_t carve_binning(void* b, size_t R, size_t mask_tiles, BinningState& s) {
+// ... or, tet only, the forward's march sequence (seq_steps steps per pixel of seq_tiles tiles, dmr_kernels.hpp; its place is
+// kept on the device too).
+size_t carve_binning(void* b, size_t R, size_t mask_tiles, size_t seq_tiles, size_t seq_steps, BinningState& s) {
     Carver c(b);
     s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
     s.capacity = (uint32_t)std::min<size_t>(R, 0xffffffffu);
     s.mask_offset = c.off;
     if (mask_tiles && R > 0) c.take<uint4>(dmr::mask_slots(R, mask_tiles) * 256);
+    s.base = reinterpret_cast<char*>(b); s.seq_offset = c.off; s.seq_steps = (uint32_t)seq_steps;
+    if (seq_steps) c.take<char>(dmr::tet_seq_bytes(seq_tiles, seq_steps));
     return c.off;
 }
 
@@ -195,7 +205,9 @@ struct SizeKey {
     int v[6];
     bool operator<(const SizeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
-struct SizeGuess { double rendered_per_face = 0.0, hits_per_face = 0.0; };
+// seq_steps: tet only -- pinned word the backward kernels leave the forward's longest march in (steps); read without any
+// wait by the next forward as its capacity estimate (a stale value only costs that call the re-marching backward)
+struct SizeGuess { double rendered_per_face = 0.0, hits_per_face = 0.0; uint32_t* seq_steps = nullptr; };
 std::mutex g_size_mu;
 std::map<SizeKey, SizeGuess> g_size_cache;
 SizeKey size_key(const dmr_scene* s, bool tet, const Dims& d) {
@@ -232,12 +244,36 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
                                is.scan_tmp, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffu), ovf, st);
         return 0;
     };
+    // tet: room for the forward's march sequence = the longest march the last backward that has run reported, + 25 % (0: none
+    // yet -- this call's backward re-marches), within a memory budget.  The pinned word is created by the first default call
+    // of the view configuration.
+    size_t seq_steps = 0;
+    if (tet) {
+        std::lock_guard<std::mutex> lk(g_size_mu);
+        SizeGuess& g = g_size_cache[size_key(s, tet, d)];
+        if (!g.seq_steps && !async) {
+            void* w = nullptr;
+            if (hipHostMalloc(&w, 64, hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess) {
+                g.seq_steps = reinterpret_cast<uint32_t*>(w);
+                *reinterpret_cast<volatile uint32_t*>(g.seq_steps) = 0u;
+            } else (void)hipGetLastError();
+        }
+        if (g.seq_steps) {
+            const uint64_t longest = *reinterpret_cast<volatile uint32_t*>(g.seq_steps);
+            if (longest) {
+                const uint64_t budget = 16ull << 30;  // bytes: beyond it the longest rays do not fit and such a call re-marches
+                const uint64_t per4 = dmr::tet_seq_bytes((size_t)d.ntiles, 4);
+                seq_steps = (size_t)(std::min<uint64_t>((longest + longest / 4 + 4 + 3) / 4, std::max<uint64_t>(budget / std::max<uint64_t>(per4, 1), 1)) * 4);
+            }
+        }
+    }
     auto rest = [&](uint64_t capacity) -> int {
         BinningState tb, bs;
         const size_t mask_tiles = tet ? 0 : (size_t)d.ntiles;
-        void* bb = alloc(ctx, DMR_BUF_BINNING, carve_binning(nullptr, (size_t)capacity, mask_tiles, tb));
-        if (!bb && capacity > 0) return fail("binning allocation failed");
-        carve_binning(bb, (size_t)capacity, mask_tiles, bs);
+        void* bb = alloc(ctx, DMR_BUF_BINNING, carve_binning(nullptr, (size_t)capacity, mask_tiles, (size_t)d.ntiles, seq_steps, tb));
+        if (!bb && (capacity > 0 || seq_steps > 0)) return fail("binning allocation failed");
+        carve_binning(bb, (size_t)capacity, mask_tiles, (size_t)d.ntiles, seq_steps, bs);
+
         if (capacity > 0) {
             dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
                                       (uint32_t)capacity, tet ? nullptr : is.mask_offset, bs.mask_offset, st);
@@ -415,7 +451,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
     carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, false, fs);
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, false, is);
-    carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, 0, bs);
+    carve_binning(const_cast<void*>(binning_buf), (size_t)num_rendered, 0, 0, 0, bs);
 
     // The forward counted the blended (pixel, face) pairs per tile and in total; the total sizes the record
     // buffer (the backward's one 8-byte host read; speculative sizing as in the forward).
@@ -516,9 +552,10 @@ int dmr_tet_forward(const dmr_scene* s, float* out_color, float* out_depth, floa
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
         dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
-                               is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec, is.seed};
+                               is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec, is.seed,
+                               is.seq, bs.base};
         const dmr_scene sc = canonical(s, is.mats);
-        dmr::launch_tet_prep(sc, img, st);
+        dmr::launch_tet_prep(sc, img, bs.seq_steps, bs.seq_offset, st);
         dmr::launch_tet_first_intersect(sc, d.gx, d.gy, d.r0, d.r1, fs.key_depth, fs.max_depth, is.tile_offset,
                                         d.ntiles > dmr::SCAN_SINGLE_MAX ? nullptr : bs.keys, bs.face_list, bs.capacity, img, st);
         dmr::launch_tet_forward(sc, d.gx, d.gy, d.r0, d.r1, img, out_color, out_depth, out_active, st);
@@ -538,10 +575,19 @@ int dmr_tet_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     ImageState is; FaceState fs;
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, true, is);
     carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, true, fs);
+    // binning_buf: the forward's march sequence lives there (where and how much of it: is.seq, on the device); a null
+    // buffer is fine when the forward ran without one (its descriptor then says cap = 0 and the backward re-marches)
     dmr::TetImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.first_face, is.first_tet,
-                           is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec, is.seed};
+                           is.last_face, is.last_tet, is.is_active, fs.facerec, fs.colrec, fs.tetrec, is.seed,
+                           is.seq, reinterpret_cast<char*>(const_cast<void*>(binning_buf))};
     const dmr_scene sc = canonical(s, is.mats);
-    dmr::launch_tet_backward(sc, d.gx, d.gy, d.r0, d.r1, img, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, st);
+    uint32_t* host_seq_steps = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_size_mu);
+        auto it = g_size_cache.find(size_key(s, true, d));
+        if (it != g_size_cache.end()) host_seq_steps = it->second.seq_steps;
+    }
+    dmr::launch_tet_backward(sc, d.gx, d.gy, d.r0, d.r1, img, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, host_seq_steps, st);
     DMR_HIP(hipGetLastError());
     return 0;
 }
@@ -612,7 +658,7 @@ int64_t dmr_export(const dmr_scene* s, int is_tet, int num_rendered, const char*
     carve_point(const_cast<void*>(point_buf), d.BP, ps);
     carve_face(const_cast<void*>(face_buf), d.BF, (size_t)s->F, (size_t)s->T, is_tet != 0, fs);
     carve_image(const_cast<void*>(image_buf), (size_t)s->B, (size_t)d.ntiles, d.npix, is_tet != 0, is);
-    carve_binning(const_cast<void*>(binning_buf), (size_t)std::max(0, num_rendered), 0, bs);
+    carve_binning(const_cast<void*>(binning_buf), (size_t)std::max(0, num_rendered), 0, 0, 0, bs);
     const std::string n(name);
     auto plain = [&](const void* src, size_t bytes) -> int64_t {
         if (dst && src && bytes) {
@@ -651,6 +697,7 @@ int64_t dmr_export(const dmr_scene* s, int is_tet, int num_rendered, const char*
         if (n == "last_face") return plain(is.last_face, d.npix * 4);
         if (n == "last_tet") return plain(is.last_tet, d.npix * 4);
         if (n == "is_active") return plain(is.is_active, d.npix);
+        if (n == "tet_seq") return plain(is.seq, 8);  // {longest march, steps the forward's march sequence had room for}
     }
     g_err = "unknown export item: " + n;
     return -1;

@@ -123,16 +123,38 @@ void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow,
                        hipStream_t st);
 
 // ---- tet ray march (dmr_tet.hip)
+// The MARCH SEQUENCE the forward leaves for the backward: the faces every pixel crossed, in order, so that the backward
+// consumes them from the back instead of re-discovering them (the reference re-marches: three ray-triangle tests and four
+// outward normals per step, cuda_renderer/backward.cu:372-476).  Static layout, no allocation on the device: wave w of the
+// forward (tile * 4 + quadrant; its 64 pixels are at the same step in the same loop iteration) owns cap_steps / 4 rows of
+// 64 x 16 bytes, step s of lane l is dword (s & 3) of the 16-byte word l of row s / 4 -- a lane stores four steps as one
+// 16-byte word, a wave's store / load of a row is one contiguous kilobyte.  The region lies in the binning buffer behind
+// the lists; cap_steps is the longest march of the previous call with the same view configuration + 25 % (dmr_api.hip; a
+// dynamic allocation of 4-KB chunks from an atomic counter was measured first: its bookkeeping inside the march loop cost
+// the forward 100 us at C3, more than the backward gained).  A sequence that did not fit (max_steps > cap_steps; cap_steps
+// == 0: no estimate yet) is ignored: the backward then re-marches like the reference.
+// Bit 31 of an entry: the reference's reverse march would stop behind this face ("error case 3": a second face of the
+// tet the ray leaves through this one is hit from outside as well, backward.cu:456-460) -- the forward has those three
+// tests in its hands anyway, so the backward reproduces the reference's decision without repeating them.
+struct TetSeq {
+    uint32_t max_steps;         // longest march of this forward (atomicMax, one per wave): complete iff <= cap_steps
+    uint32_t cap_steps;         // steps per pixel the region has room for (a multiple of 4; 0: no region)
+    unsigned long long offset;  // bytes from the binning buffer's start
+};
+inline size_t tet_seq_bytes(size_t ntiles, size_t cap_steps) { return ntiles * 4 * (cap_steps / 4) * 1024; }
 struct TetImageState {
     float* final_log_T; float* final_prev_log_T; uint32_t* n_contrib;
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     void* facerec; void* colrec; void* tetrec;  // packed march records (dmr_tet.hip), in the face buffer
     int* seed;                                  // ray_random_seed of the forward (image buffer)
+    TetSeq* seq;                                // the march sequence's descriptor (image buffer)
+    char* binning;                              // start of the binning buffer (the sequence region lies at seq->offset)
 };
 size_t tet_facerec_bytes();
 size_t tet_colrec_bytes();
-// builds the packed march records from the scene (every forward call)
-void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st);
+// builds the packed march records from the scene (every forward call); also resets the march sequence's descriptor:
+// room for seq_steps steps per pixel at byte seq_offset of the binning buffer
+void launch_tet_prep(const dmr_scene& s, TetImageState img, uint32_t seq_steps, unsigned long long seq_offset, hipStream_t st);
 // keys: as launch_tri_forward (non-null: every tile's workgroup sorts its list itself)
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
                                 const float* max_depth, const uint32_t* tile_offset, uint64_t* keys, uint32_t* face_list,
@@ -140,8 +162,11 @@ void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int 
 void launch_tet_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
                         float* out_color, float* out_depth, float* out_active, hipStream_t st);
 void launch_tet_zero_grads(float* dL_dvcolor, int64_t n_vcolor, float* dL_dfopacity, int64_t n_fopacity, hipStream_t st);
+// Two launches, of which the device runs one: k_tet_backward_seq when the forward's march sequence is complete
+// (seq->max_steps <= seq->cap_steps != 0), else the re-marching k_tet_backward; the other one returns at once.  No host read.
+// host_seq_steps (pinned, may be null): receives seq->max_steps, the next forward's capacity estimate.
 void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dvcolor, float* dL_dfopacity,
-                         hipStream_t st);
+                         uint32_t* host_seq_steps, hipStream_t st);
 
 }  // namespace dmr

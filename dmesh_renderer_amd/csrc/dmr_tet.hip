@@ -59,9 +59,12 @@ __global__ void __launch_bounds__(256)
 k_tet_prep_faces(int F, const float* __restrict__ verts, const int* __restrict__ faces,
                  const float* __restrict__ verts_color, const float* __restrict__ faces_opacity,
                  const int* __restrict__ face_tets, TetFaceRec* __restrict__ facerec, TetColRec* __restrict__ colrec,
-                 int seed, int* __restrict__ seed_slot) {
+                 int seed, int* __restrict__ seed_slot, TetSeq* __restrict__ seq, uint32_t seq_steps, unsigned long long seq_offset) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f == 0) *seed_slot = seed;
+    if (f == 0) {
+        *seed_slot = seed;
+        seq->max_steps = 0u; seq->cap_steps = seq_steps; seq->offset = seq_offset;  // the march sequence of this forward (dmr_kernels.hpp)
+    }
     if (f >= F) return;
     const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
     const V3 p0 = load_v3(verts, v0), p1 = load_v3(verts, v1), p2 = load_v3(verts, v2);
@@ -218,9 +221,14 @@ __device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int f
 // One march step shared by forward (FWD: leave through the face whose outward normal follows
 // the ray) and backward (enter face: normal against the ray).  Returns false when the march
 // must stop ("error cases" 1-3 of the reference).
+// FWD only, `back_amb`: one of the tet's other faces is hit with its outward normal AGAINST the ray, i.e. the reference's
+// reverse march, arriving in this tet through the face chosen here, would find a second candidate next to the face the
+// forward came in through and stop ("error case 3", backward.cu:456-460).  Same tests, same bits: the forward's entry face
+// always qualifies there (it was accepted as a hit with this ray, and its normal is checked below), so this flag is all the
+// backward needs to know of this tet.
 template <bool FWD>
 __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet,
-                                           float& curr_rt, float& curr_iu, float& curr_iv, V3& curr_n) {
+                                           float& curr_rt, float& curr_iu, float& curr_iv, V3& curr_n, bool* back_amb = nullptr) {
     const int4 tr = p.tetrec[curr_tet];
     // The three faces of the tet other than the current one, in the record's order, with their orientation bits --
     // by selects, not by indexing small arrays (which the compiler put in scratch memory: 12 scratch accesses per step).
@@ -245,6 +253,7 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     int nf = -1, ncnt = 0, nft0 = -1, nft1 = -1;
     float nrt = 0, niu = 0, niv = 0;
     V3 nn = {0, 0, 0};
+    bool amb = false;
     auto test = [&](const TetFaceRec& r, int of, bool flip, bool val) {
         V3 tuv;
         const bool hit = ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
@@ -253,11 +262,15 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
         if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) {
             nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; nn = {r.n[0], r.n[1], r.n[2]}; ncnt++;
         }
+#ifndef DMR_TET_NO_AMB
+        if (FWD && hit && dn < 0.0f) amb = true;
+#endif
     };
     test(r0, others0, oflip0, oval0);
     test(r1, others1, oflip1, oval1);
     test(r2, others2, oflip2, oval2);
     if (ncnt != 1 || !ok) return false;
+    if (FWD && back_amb) *back_amb = amb;
     int nt = -1;
     if (!(nft0 == curr_tet || nft0 == -1)) nt = nft0;
     else if (!(nft1 == curr_tet || nft1 == -1)) nt = nft1;
@@ -265,18 +278,36 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     return true;
 }
 
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {  // all 64 lanes must be active
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, dlt, 64));
+    return v;
+}
+
+#ifndef DMR_TET_FWD_WAVES
+#define DMR_TET_FWD_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, DMR_TET_FWD_WAVES)
 k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_active) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
     const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
-    if (px >= p.W || py >= p.H) return;
+    const bool inside = px < p.W && py < p.H;  // (lanes outside stay for the wave-level bookkeeping of the march sequence)
     const int64_t HW = (int64_t)p.H * p.W, pix_id = (int64_t)p.W * py + px, bpix = (int64_t)b * HW + pix_id;
-    V3 ro, rd;
-    pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
+    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    int first_face = -1, first_tet = -1;
+    if (inside) {
+        pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
+        first_face = p.img.first_face[bpix]; first_tet = p.img.first_tet[bpix];
+    }
     const float* mv = p.mv + 16 * b;
     const float* pr = p.proj + 16 * b;
-    const int first_face = p.img.first_face[bpix], first_tet = p.img.first_tet[bpix];
 
     bool done = false;
     int curr_face = first_face, curr_tet = first_tet;
@@ -285,13 +316,29 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     if (first_face == -1 || first_tet == -1) done = true;
     else face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv, curr_n);
 
+    // the march sequence (dmr_kernels.hpp): this lane's 16-byte words, one per four steps, 64 words apart
+    const uint32_t seq_cap = p.img.seq->cap_steps;
+    uint4* const seq_row = reinterpret_cast<uint4*>(p.img.binning + p.img.seq->offset) +
+                           ((((size_t)b * p.gy + ty) * p.gx + tx) * 4 + wave) * (size_t)(seq_cap / 4u) * 64u + (uint32_t)lane;
+    bool back_amb = false;
+
     V3 C = {0, 0, 0};
     float D = 0.f, log_T = 0.f, prev_log_T = 0.f;
     float T_cur = expf(log_T);  // expf(log_T), carried from step to step (the reference evaluates it twice per step)
     int last_face = -1, last_tet = -1;
     bool active = false;
     uint32_t n_contrib = 0;
+    // One 4-byte store per step, straight to the lane's dword of the row (measured at C3, k_tet_forward: no sequence 213 us,
+    // this 225; four entries kept in registers and stored as one 16-byte word every fourth step: 272 -- with or without the
+    // store itself, the selects that pick the register cost more than three stores).
+    auto seq_put = [&](uint32_t s, int face, bool amb) {  // entry s of this lane
+        if (s < seq_cap) reinterpret_cast<uint32_t*>(seq_row + (size_t)(s >> 2) * 64u)[s & 3u] = (uint32_t)face | (amb ? 0x80000000u : 0u);
+    };
+#ifndef DMR_TET_SEQ_MODE
+#define DMR_TET_SEQ_MODE 1
+#endif
     while (!done) {
+        if (DMR_TET_SEQ_MODE == 1) seq_put(n_contrib, curr_face, back_amb);
         const float4* cq = reinterpret_cast<const float4*>(p.colrec + curr_face);
         const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2], cq3 = cq[3];
         const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
@@ -314,8 +361,13 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         last_face = curr_face;
         last_tet = curr_tet;
         if (curr_tet == -1) { active = true; done = true; }
-        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
+        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n, &back_amb)) done = true;
     }
+    if (DMR_TET_SEQ_MODE != 0) {   // the wave's longest march (complete sequence? the next call's estimate)
+        const uint32_t steps = wave_max_u32(n_contrib);
+        if (lane == 0 && steps != 0u) atomicMax(&p.img.seq->max_steps, steps);
+    }
+    if (!inside) return;
     p.img.final_log_T[bpix] = log_T;
     p.img.final_prev_log_T[bpix] = prev_log_T;
     p.img.last_face[bpix] = last_face;
@@ -363,9 +415,191 @@ struct TetAccum {
     }
 };
 
+// One pixel's state of the reverse walk and the gradient of one marched face (cuda_renderer/backward.cu:236-360),
+// shared by the two backward kernels: k_tet_backward re-marches like the reference, k_tet_backward_seq takes the faces
+// from the forward's march sequence.
+struct TetBwdPixel {
+    float dpc0, dpc1, dpc2, dpd, bg_dot, bd_dot, final_prev_T, final_T, prev_log_T;
+    float last_alpha, lc0, lc1, lc2, ar0, ar1, ar2, last_depth, ard;
+    bool first_iter;
+    // -> g[0..8] = dL/d(vertex colours of the face), g[9] = dL/d(opacity); v0..v2: the face's vertices
+    __device__ __forceinline__ void face_grad(const TetParams& p, int b, int face, V3 ro, V3 rd, const float* __restrict__ mv,
+                                              const float* __restrict__ pr, float rt, float iu, float iv, float (&g)[10],
+                                              int& v0, int& v1, int& v2) {
+        const float4* cq = reinterpret_cast<const float4*>(p.colrec + face);
+        face_grad(ro, rd, mv, pr, rt, iu, iv, cq[0], cq[1], cq[2], cq[3], p.faces_intense[(int64_t)b * p.F + face], g, v0, v1, v2);
+    }
+    __device__ __forceinline__ void face_grad(V3 ro, V3 rd, const float* __restrict__ mv, const float* __restrict__ pr, float rt,
+                                              float iu, float iv, float4 cq0, float4 cq1, float4 cq2, float4 cq3, float intense,
+                                              float (&g)[10], int& v0, int& v1, int& v2) {
+        const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
+        v0 = __float_as_int(cq2.y); v1 = __float_as_int(cq2.z); v2 = __float_as_int(cq2.w);
+        const float i0 = 1.0f - iu - iv, i1 = iu, i2 = iv;
+        V3 col = (i0 * c0) + (i1 * c1) + (i2 * c2);  // Q21
+        const float opacity = cq3.x;
+        col = col * intense;
+        const V3 pt = ro + (rd * rt);
+        const V4 pn = xform4x4(xform4x3(pt, mv), pr);
+        const float pw = 1.0f / clamp_w(pn.w);
+        const float pdepth = pn.z * pw;
+        if (!first_iter) prev_log_T = prev_log_T - cq3.y;  // logf(1 - opacity), per face (TetColRec)
+        first_iter = false;
+        const float prev_T = expf(prev_log_T);
+
+        float dop = 0.f;
+        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = col.x;
+        const float dc0 = dpc0 * opacity * prev_T; dop += (col.x - ar0) * dpc0;
+        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = col.y;
+        const float dc1 = dpc1 * opacity * prev_T; dop += (col.y - ar1) * dpc1;
+        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = col.z;
+        const float dc2 = dpc2 * opacity * prev_T; dop += (col.z - ar2) * dpc2;
+        ard = last_alpha * last_depth + (1.f - last_alpha) * ard; last_depth = pdepth;
+        dop += (pdepth - ard) * dpd;
+        dop *= prev_T;
+        last_alpha = opacity;
+        if (opacity == 1.0f) {
+            dop += (-final_prev_T) * bg_dot;
+            dop += (-final_prev_T) * bd_dot;
+        } else {
+            dop += (-final_T / (1.f - opacity)) * bg_dot;
+            dop += (-final_T / (1.f - opacity)) * bd_dot;
+        }
+        g[0] = i0 * dc0 * intense; g[1] = i0 * dc1 * intense; g[2] = i0 * dc2 * intense;
+        g[3] = i1 * dc0 * intense; g[4] = i1 * dc1 * intense; g[5] = i1 * dc2 * intense;
+        g[6] = i2 * dc0 * intense; g[7] = i2 * dc1 * intense; g[8] = i2 * dc2 * intense;
+        g[9] = dop;
+    }
+};
+
+// Adds the wave's (pixel, face) gradients of one step to the tile's table.  Called by ALL lanes of the wave (`act`: this lane
+// has a gradient).  Neighbouring pixels march through the same faces in near lockstep, so the lanes of a wave pile onto a few
+// table cells, and same-address LDS atomics serialise (profiles/r03: the LDS was busy 93 % of the kernel, 81 % of that
+// in conflict cycles).  So lanes that hold the same face first merge pairwise, four butterfly levels inside a 16-lane
+// DPP row (lane ^ 1, ^ 2 by quad_perm, + 4, + 8 by row shifts): at every level a live lane whose partner is alive with the
+// same face takes the partner's ten values and the partner retires -- whatever the faces' layout over the lanes (round 2
+// merged only aligned quads / octets / rows that were uniform).  What is still alive goes to the table.  Values are moved
+// with selects, not multiplied by 0/1 masks: a non-finite gradient must not leak into another face's sums.
+// One level: g += m * g[partner] with m = 1.0 where this lane takes its partner's values, else 0.0 -- one v_fmac_f32_dpp per
+// value (a select + add is three instructions, and the DPP forms are half rate: 120 of this kernel's 530 VALU instructions per
+// step were these merges).  Non-finite values never get here (tet_accumulate takes such lanes out first): 0 * inf would
+// leak NaN into the partner's face.
+#define DMR_TET_FMAC(N, DPP) "v_fmac_f32_dpp %[g" #N "], %[g" #N "], %[m] " DPP "\n\t"
+#define DMR_TET_MERGE(DPP)                                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                                          \
+                 DMR_TET_FMAC(0, DPP) DMR_TET_FMAC(1, DPP) DMR_TET_FMAC(2, DPP) DMR_TET_FMAC(3, DPP) DMR_TET_FMAC(4, DPP)  \
+                 DMR_TET_FMAC(5, DPP) DMR_TET_FMAC(6, DPP) DMR_TET_FMAC(7, DPP) DMR_TET_FMAC(8, DPP) DMR_TET_FMAC(9, DPP)  \
+                 : [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]),                  \
+                   [g5] "+v"(g[5]), [g6] "+v"(g[6]), [g7] "+v"(g[7]), [g8] "+v"(g[8]), [g9] "+v"(g[9])                   \
+                 : [m] "v"(m))
+template <int LEVEL>
+__device__ __forceinline__ void tet_merge_level(int lane, int& key, float (&g)[10]) {
+    constexpr int offset = 1 << LEVEL;
+    constexpr int FROM_UPPER = LEVEL == 0 ? 0xB1 : (LEVEL == 1 ? 0x4E : (LEVEL == 2 ? 0x104 : 0x108));  // quad_perm ^1, ^2; row_shl:4, :8
+    constexpr int FROM_LOWER = LEVEL == 0 ? 0xB1 : (LEVEL == 1 ? 0x4E : (LEVEL == 2 ? 0x114 : 0x118));  // ... row_shr:4, :8
+    const bool lower = (lane & offset) == 0;
+    const int k_up = __builtin_amdgcn_update_dpp(-1, key, FROM_UPPER, 0xF, 0xF, false);   // key of lane + offset (as seen by lower lanes)
+    const int k_lo = __builtin_amdgcn_update_dpp(-1, key, FROM_LOWER, 0xF, 0xF, false);   // key of lane - offset (as seen by upper lanes)
+    const float m = (lower && key >= 0 && k_up == key) ? 1.0f : 0.0f;
+    const bool retire = !lower && key >= 0 && k_lo == key;
+    if (LEVEL == 0) DMR_TET_MERGE("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    else if (LEVEL == 1) DMR_TET_MERGE("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    else if (LEVEL == 2) DMR_TET_MERGE("row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    else DMR_TET_MERGE("row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    if (retire) key = -1;  // its values went to the partner (what it still holds is finite and is taken by nobody: its key says so)
+}
+
+__device__ __forceinline__ void tet_direct_atomics(const float (&g)[10], int face, int v0, int v1, int v2, float* __restrict__ dL_dvcolor,
+                                                   float* __restrict__ dL_dfopacity) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        atomicAdd(&dL_dvcolor[3 * v0 + c], g[c]);
+        atomicAdd(&dL_dvcolor[3 * v1 + c], g[3 + c]);
+        atomicAdd(&dL_dvcolor[3 * v2 + c], g[6 + c]);
+    }
+    atomicAdd(&dL_dfopacity[face], g[9]);
+}
+
+__device__ __forceinline__ void tet_accumulate(const TetParams& p, const TetAccum& acc, double (*s_val)[TET_TBL], int lane, bool act,
+                                               int face, float (&g)[10], int v0, int v1, int v2, float* __restrict__ dL_dvcolor,
+                                               float* __restrict__ dL_dfopacity) {
+    if (act) {  // a lane with a non-finite value adds its ten values the reference's way and takes no part in the merges
+        float chk = 0.f;
+#pragma unroll
+        for (int c = 0; c < 10; c++) chk = fmaf(g[c], 0.f, chk);
+        if (!(chk == 0.f)) { tet_direct_atomics(g, face, v0, v1, v2, dL_dvcolor, dL_dfopacity); act = false; }
+    }
+    int key = act ? face : -1;  // -1: nothing (left) in this lane
+    if (!act) {
+#pragma unroll
+        for (int c = 0; c < 10; c++) g[c] = 0.f;
+    }
+    tet_merge_level<0>(lane, key, g);
+    tet_merge_level<1>(lane, key, g);
+    tet_merge_level<2>(lane, key, g);
+    tet_merge_level<3>(lane, key, g);
+    if (key < 0) return;
+    // (ablation build, DMR_ABLATE bit 2048, tests only: odd faces are refused a slot, which exercises the direct-atomic fallback)
+    const int slot = (DMR_DBG(p, 2048) && (face & 1)) ? -1 : acc.find(face);
+    if (slot >= 0) {
+#pragma unroll
+        for (int c = 0; c < 10; c++) atomicAdd(&s_val[c][slot], (double)g[c]);
+    } else {
+        tet_direct_atomics(g, face, v0, v1, v2, dL_dvcolor, dL_dfopacity);
+    }
+}
+
+// flush of the tile's table: 16 lanes per slot (10 used): lanes 0-8 -> the three vertex-colour rows, lane 9 -> opacity
+__device__ __forceinline__ void tet_flush(const TetParams& p, const int* s_key, double (*s_val)[TET_TBL], int tid,
+                                          float* __restrict__ dL_dvcolor, float* __restrict__ dL_dfopacity) {
+    const int sub = tid & 15;
+    for (int s0 = 0; s0 < TET_TBL; s0 += 16) {
+        const int slot = s0 + (tid >> 4);
+        const int face = s_key[slot];
+        if (face < 0 || sub > 9) continue;
+        const float v = (float)s_val[sub][slot];
+        if (sub < 9) atomicAdd(&dL_dvcolor[3 * p.faces[3 * face + sub / 3] + sub % 3], v);
+        else atomicAdd(&dL_dfopacity[face], v);
+    }
+}
+
+// what a pixel's reverse walk starts from; false: the pixel has no gradient (outside, inactive, nothing marched)
+__device__ __forceinline__ bool tet_bwd_begin(const TetParams& p, int b, int px, int py, const float* __restrict__ dL_dcolor,
+                                              const float* __restrict__ dL_ddepth, TetBwdPixel& st, V3& ro, V3& rd,
+                                              int& first_face, int& last_face) {
+    const int64_t HW = (int64_t)p.H * p.W, pix_id = (int64_t)p.W * py + px, bpix = (int64_t)b * HW + pix_id;
+    bool work = px < p.W && py < p.H;
+    if (work) work = p.img.is_active[bpix] != 0;
+    last_face = -1;
+    if (work) { last_face = p.img.last_face[bpix]; work = last_face != -1; }
+    if (!work) return false;
+    first_face = p.img.first_face[bpix];
+    const float fprev = p.img.final_prev_log_T[bpix], flog = p.img.final_log_T[bpix];
+    st.final_prev_T = expf(fprev); st.final_T = expf(flog);
+    st.prev_log_T = fprev;
+    st.dpc0 = dL_dcolor[((int64_t)b * 3 + 0) * HW + pix_id];
+    st.dpc1 = dL_dcolor[((int64_t)b * 3 + 1) * HW + pix_id];
+    st.dpc2 = dL_dcolor[((int64_t)b * 3 + 2) * HW + pix_id];
+    st.dpd = dL_ddepth[bpix];
+    float bg_dot = 0.f;
+    bg_dot += p.bg[0] * st.dpc0; bg_dot += p.bg[1] * st.dpc1; bg_dot += p.bg[2] * st.dpc2;
+    st.bg_dot = bg_dot;
+    st.bd_dot = 0.f + (float)(1.0 * (double)st.dpd);
+    st.last_alpha = 0.f; st.lc0 = st.lc1 = st.lc2 = 0.f; st.ar0 = st.ar1 = st.ar2 = 0.f; st.last_depth = 0.f; st.ard = 0.f;
+    st.first_iter = true;
+    pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
+    return true;
+}
+
+// The re-marching backward (the reference's algorithm): the fallback when the forward's march sequence is not there --
+// no capacity estimate yet (first call of a view configuration) or a scene that outgrew it.  Decided on the device:
+// both kernels are always launched and one of them returns at once.
 __global__ void __launch_bounds__(256)
 k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                float* __restrict__ dL_dvcolor, float* __restrict__ dL_dfopacity) {
+    {
+        const uint32_t cap = p.img.seq->cap_steps;
+        if (cap != 0u && p.img.seq->max_steps <= cap && !DMR_DBG(p, 8192)) return;  // uniform: k_tet_backward_seq does this call's work
+    }
     __shared__ int s_key[TET_TBL];
     __shared__ double s_val[10][TET_TBL];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -379,32 +613,17 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
 
     const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
     const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
-    const int64_t HW = (int64_t)p.H * p.W, pix_id = (int64_t)p.W * py + px, bpix = (int64_t)b * HW + pix_id;
-    bool work = px < p.W && py < p.H;
-    if (work) work = p.img.is_active[bpix] != 0;
-    int last_face = -1;
-    if (work) { last_face = p.img.last_face[bpix]; work = last_face != -1; }
-    if (work) {
-        const int first_face = p.img.first_face[bpix];
-        const float fprev = p.img.final_prev_log_T[bpix], flog = p.img.final_log_T[bpix];
-        const float final_prev_T = expf(fprev), final_T = expf(flog);
-        float prev_log_T = fprev;
-        const float dpc0 = dL_dcolor[((int64_t)b * 3 + 0) * HW + pix_id];
-        const float dpc1 = dL_dcolor[((int64_t)b * 3 + 1) * HW + pix_id];
-        const float dpc2 = dL_dcolor[((int64_t)b * 3 + 2) * HW + pix_id];
-        const float dpd = dL_ddepth[bpix];
-        float bg_dot = 0.f;
-        bg_dot += p.bg[0] * dpc0; bg_dot += p.bg[1] * dpc1; bg_dot += p.bg[2] * dpc2;
-        const float bd_dot = 0.f + (float)(1.0 * (double)dpd);
-
-        V3 ro, rd;
-        pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
-        const float* mv = p.mv + 16 * b;
-        const float* pr = p.proj + 16 * b;
-
-        int curr_face = last_face, curr_tet = p.img.last_tet[bpix];
-        float curr_rt, curr_iu, curr_iv;
-        V3 curr_n;
+    TetBwdPixel st;
+    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    int first_face = -1, last_face = -1;
+    bool done = !tet_bwd_begin(p, b, px, py, dL_dcolor, dL_ddepth, st, ro, rd, first_face, last_face);
+    const float* mv = p.mv + 16 * b;
+    const float* pr = p.proj + 16 * b;
+    int curr_face = last_face, curr_tet = -1;
+    float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
+    V3 curr_n = {0, 0, 0};
+    if (!done) {
+        curr_tet = p.img.last_tet[(int64_t)b * p.H * p.W + (int64_t)p.W * py + px];
         face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv, curr_n);
         // step back across the last face (backward.cu:223-232)
         for (int i = 0; i < 2; i++) {
@@ -413,116 +632,123 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
             curr_tet = t;
             break;
         }
-        float last_alpha = 0.f, lc0 = 0, lc1 = 0, lc2 = 0, ar0 = 0, ar1 = 0, ar2 = 0, last_depth = 0.f, ard = 0.f;
-        bool first_iter = true, done = false;
-        while (!done) {
-            const float4* cq = reinterpret_cast<const float4*>(p.colrec + curr_face);
-            const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2], cq3 = cq[3];
-            const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
-            const int v0 = __float_as_int(cq2.y), v1 = __float_as_int(cq2.z), v2 = __float_as_int(cq2.w);
-            const float i0 = 1.0f - curr_iu - curr_iv, i1 = curr_iu, i2 = curr_iv;
-            V3 col = (i0 * c0) + (i1 * c1) + (i2 * c2);  // Q21
-            const float opacity = cq3.x;
-            const float intense = p.faces_intense[(int64_t)b * p.F + curr_face];
-            col = col * intense;
-            const V3 pt = ro + (rd * curr_rt);
-            const V4 pn = xform4x4(xform4x3(pt, mv), pr);
-            const float pw = 1.0f / clamp_w(pn.w);
-            const float pdepth = pn.z * pw;
-            if (!first_iter) prev_log_T = prev_log_T - cq3.y;  // logf(1 - opacity), per face (TetColRec)
-            first_iter = false;
-            const float prev_T = expf(prev_log_T);
-
-            float dop = 0.f;
-            ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = col.x;
-            const float dc0 = dpc0 * opacity * prev_T; dop += (col.x - ar0) * dpc0;
-            ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = col.y;
-            const float dc1 = dpc1 * opacity * prev_T; dop += (col.y - ar1) * dpc1;
-            ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = col.z;
-            const float dc2 = dpc2 * opacity * prev_T; dop += (col.z - ar2) * dpc2;
-            ard = last_alpha * last_depth + (1.f - last_alpha) * ard; last_depth = pdepth;
-            dop += (pdepth - ard) * dpd;
-            dop *= prev_T;
-            last_alpha = opacity;
-            if (opacity == 1.0f) {
-                dop += (-final_prev_T) * bg_dot;
-                dop += (-final_prev_T) * bd_dot;
-            } else {
-                dop += (-final_T / (1.f - opacity)) * bg_dot;
-                dop += (-final_T / (1.f - opacity)) * bd_dot;
-            }
-            float g[10] = {i0 * dc0 * intense, i0 * dc1 * intense, i0 * dc2 * intense,
-                           i1 * dc0 * intense, i1 * dc1 * intense, i1 * dc2 * intense,
-                           i2 * dc0 * intense, i2 * dc1 * intense, i2 * dc2 * intense, dop};
-            // Neighbouring pixels march through the same faces in near lockstep, so the lanes of a wave pile onto a few
-            // table cells (same-address LDS atomics serialise: 0.13 of this kernel's 0.52 ms at C3).  When the four
-            // lanes of a DPP quad (four pixels in a row) hold the same face in this step, they add their values with
-            // two quad_perm exchanges and one lane goes to the table.  Lanes outside the loop read as "no face".
-            const int k1 = __builtin_amdgcn_update_dpp(-1, curr_face, 0xB1, 0xF, 0xF, false);  // lane ^ 1
-            const int k2 = __builtin_amdgcn_update_dpp(-1, curr_face, 0x4E, 0xF, 0xF, false);  // lane ^ 2
-            const int k3 = __builtin_amdgcn_update_dpp(-1, k1, 0x4E, 0xF, 0xF, false);         // lane ^ 3
-            const bool quad = k1 == curr_face && k2 == curr_face && k3 == curr_face;
-            if (quad) {
-#pragma unroll
-                for (int c = 0; c < 10; c++) {
-                    float t = g[c];
-                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, false));
-                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, false));
-                    g[c] = t;
-                }
-            }
-            // ... then two such quads (row_half_mirror: 8 pixels in a row), then two such octets (row_mirror: two pixel
-            // rows), each time only if both halves are uniform and hold the same face.
-            const int kq = quad ? curr_face : -1;
-            const bool oct = quad && __builtin_amdgcn_update_dpp(-1, kq, 0x141, 0xF, 0xF, false) == curr_face;
-            if (oct) {
-#pragma unroll
-                for (int c = 0; c < 10; c++)
-                    g[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g[c]), 0x141, 0xF, 0xF, false));
-            }
-            const int ko = oct ? curr_face : -1;
-            const bool hex = oct && __builtin_amdgcn_update_dpp(-1, ko, 0x140, 0xF, 0xF, false) == curr_face;
-            if (hex) {
-#pragma unroll
-                for (int c = 0; c < 10; c++)
-                    g[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g[c]), 0x140, 0xF, 0xF, false));
-            }
-            const bool follower = hex ? (lane & 15) != 0 : (oct ? (lane & 7) != 0 : (quad && (lane & 3) != 0));
-            // (ablation build, DMR_ABLATE bit 2048, tests only: odd faces are refused a slot, which exercises the direct-atomic fallback)
-            const int slot = follower ? -2 : ((DMR_DBG(p, 2048) && (curr_face & 1)) ? -1 : acc.find(curr_face));
-            if (slot == -2) {
-                // this lane's values went out with the first lane of its quad / octet / row
-            } else if (slot >= 0) {
-#pragma unroll
-                for (int c = 0; c < 10; c++) atomicAdd(&s_val[c][slot], (double)g[c]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    atomicAdd(&dL_dvcolor[3 * v0 + c], g[c]);
-                    atomicAdd(&dL_dvcolor[3 * v1 + c], g[3 + c]);
-                    atomicAdd(&dL_dvcolor[3 * v2 + c], g[6 + c]);
-                }
-                atomicAdd(&dL_dfopacity[curr_face], g[9]);
-            }
-
+    }
+    while (!__all(done)) {  // the wave's lanes stay together: tet_accumulate merges lanes that hold the same face
+        const bool act = !done;
+        float g[10];
+        int v0 = 0, v1 = 0, v2 = 0;
+        const int face = curr_face;
+        if (act) {
+            st.face_grad(p, b, curr_face, ro, rd, mv, pr, curr_rt, curr_iu, curr_iv, g, v0, v1, v2);
             if (curr_face == first_face) done = true;
             if (!done) {
                 if (curr_tet == -1) done = true;
                 else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
             }
         }
+        tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
     }
     __syncthreads();
-    // flush: 16 lanes per slot (10 used): lanes 0-8 -> the three vertex-colour rows, lane 9 -> opacity
-    const int sub = tid & 15;
-    for (int s0 = 0; s0 < TET_TBL; s0 += 16) {
-        const int slot = s0 + (tid >> 4);
-        const int face = s_key[slot];
-        if (face < 0 || sub > 9) continue;
-        const float v = (float)s_val[sub][slot];
-        if (sub < 9) atomicAdd(&dL_dvcolor[3 * p.faces[3 * face + sub / 3] + sub % 3], v);
-        else atomicAdd(&dL_dfopacity[face], v);
+    tet_flush(p, s_key, s_val, tid, dL_dvcolor, dL_dfopacity);
+}
+
+// The backward on the forward's march sequence (dmr_kernels.hpp): a wave walks its rows from the back, step s of all its
+// pixels in the same iteration (a pixel joins at its own last step), one contiguous kilobyte per four steps.  Per step and
+// pixel: ONE ray-triangle evaluation for (t, u, v) -- the same function on the same operands as the reference's reverse
+// march computes for the face it picked, so the values are the same bits -- instead of the tet record, three candidate
+// records, three tests and the orientation logic.  Stops where the reference stops: behind first_face, or behind an entry
+// whose bit 31 says the reverse march would find two candidates there.
+__global__ void __launch_bounds__(256)
+k_tet_backward_seq(TetParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                   float* __restrict__ dL_dvcolor, float* __restrict__ dL_dfopacity, uint32_t* __restrict__ host_seq_steps) {
+    const uint32_t seq_cap = p.img.seq->cap_steps, longest = p.img.seq->max_steps;
+    if (host_seq_steps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        *host_seq_steps = longest;  // pinned: the next forward's capacity estimate (whichever kernel does the work)
+    if (seq_cap == 0u || longest > seq_cap || DMR_DBG(p, 8192)) return;  // uniform: no complete sequence, k_tet_backward re-marches
+    __shared__ int s_key[TET_TBL];
+    __shared__ double s_val[10][TET_TBL];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < TET_TBL; i += 256) {
+        s_key[i] = -1;
+#pragma unroll
+        for (int c = 0; c < 10; c++) s_val[c][i] = 0.0;
     }
+    __syncthreads();
+    const TetAccum acc{s_key, s_val};
+
+    const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    TetBwdPixel st;
+    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    int first_face = -1, last_face = -1;
+    const bool work = tet_bwd_begin(p, b, px, py, dL_dcolor, dL_ddepth, st, ro, rd, first_face, last_face);
+    const uint32_t n = work ? min(p.img.n_contrib[(int64_t)b * p.H * p.W + (int64_t)p.W * py + px], seq_cap) : 0u;
+    const uint32_t smax = wave_max_u32(n);  // the wave's first step from the back
+    const uint4* const seq_row = reinterpret_cast<const uint4*>(p.img.binning + p.img.seq->offset) +
+                                 ((((size_t)b * p.gy + ty) * p.gx + tx) * 4 + wave) * (size_t)(seq_cap / 4u) * 64u + (uint32_t)lane;
+    if (smax != 0u) {  // (uniform per wave)
+        const float* mv = p.mv + 16 * b;
+        const float* pr = p.proj + 16 * b;
+        // The load stream runs ahead of the arithmetic: the sequence says which records step s - 1 needs while step s is
+        // being computed (the reference's -- and the fallback's -- reverse march cannot know: there a step is a chain of
+        // dependent gathers, tet record -> three face records -> tests -> colour record).
+        struct Recs { float4 f0, f1, f2, c0, c1, c2, c3; float intense; };
+        auto load_recs = [&](uint32_t e, Recs& r) {
+            if (e == 0xffffffffu) return;  // this lane has no such step (not joined yet, or below step 0)
+            const int face = (int)(e & 0x7fffffffu);
+            const float4* fq = reinterpret_cast<const float4*>(p.facerec + face);
+            const float4* cq = reinterpret_cast<const float4*>(p.colrec + face);
+            r.f0 = fq[0]; r.f1 = fq[1]; r.f2 = fq[2];
+            r.c0 = cq[0]; r.c1 = cq[1]; r.c2 = cq[2]; r.c3 = cq[3];
+            r.intense = p.faces_intense[(int64_t)b * p.F + face];
+        };
+        // entry t of this lane out of the row word it belongs to; never an id that is not a face's (-> "no such step")
+        auto entry = [&](const uint4& w, int t) -> uint32_t {
+            if (t < 0 || (uint32_t)t >= n) return 0xffffffffu;
+            const uint32_t q = (uint32_t)t & 3u;
+            const uint32_t e = q == 0u ? w.x : (q == 1u ? w.y : (q == 2u ? w.z : w.w));
+            return (e & 0x7fffffffu) < (uint32_t)p.F ? e : 0xffffffffu;
+        };
+        auto load_row = [&](int t) -> uint4 {  // the row word of step t (uniform t; only lanes that have a step in that row read)
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (t >= 0 && ((uint32_t)t & ~3u) < n) w = seq_row[(size_t)((uint32_t)t >> 2) * 64u];
+            return w;
+        };
+        Recs rc = {}, rn = {};
+        uint4 w_cur = load_row((int)smax - 1);                     // row of the step being prepared (s - 1 below)
+        uint4 w_nxt = load_row((((int)smax - 1) & ~3) - 1);        // the row below it, requested a row ahead
+        uint32_t e_cur = entry(w_cur, (int)smax - 1);
+        load_recs(e_cur, rc);
+        bool done = !work;
+        // one step: computes step s from `cur` while the records of step s - 1 arrive in `nxt`; true: the wave is finished.
+        // (Two record sets used alternately: rotating one into the other was 29 register moves per step.  A ring of three,
+        // two steps ahead: 175 VGPRs, 367 -> 400 us at C3 -- the latency is hidden at distance one.)
+        auto one = [&](int s, const Recs& cur, Recs& nxt) -> bool {
+            // the entry of step s - 1 comes from w_cur, or from w_nxt when s - 1 is the last step of the row below
+            if ((s & 3) == 0) { w_cur = w_nxt; w_nxt = load_row(s - 5); }
+            const uint32_t e_nxt = entry(w_cur, s - 1);
+            load_recs(done ? 0xffffffffu : e_nxt, nxt);             // in flight during step s
+            const bool act = !done && e_cur != 0xffffffffu;
+            const int face = (int)(e_cur & 0x7fffffffu);
+            float g[10];
+            int v0 = 0, v1 = 0, v2 = 0;
+            if (act) {
+                V3 tuv = {0, 0, 0};  // (t, u, v): the same function on the same operands as the reverse march evaluates
+                ray_tri_hit(ro, rd, {cur.f0.x, cur.f0.y, cur.f0.z}, {cur.f0.w, cur.f1.x, cur.f1.y}, {cur.f1.z, cur.f1.w, cur.f2.x}, tuv);
+                st.face_grad(ro, rd, mv, pr, tuv.x, tuv.y, tuv.z, cur.c0, cur.c1, cur.c2, cur.c3, cur.intense, g, v0, v1, v2);
+                if (face == first_face || (e_cur & 0x80000000u)) done = true;
+            }
+            tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
+            e_cur = e_nxt;
+            return __all(done);
+        };
+        for (int s = (int)smax - 1; s >= 0; s -= 2) {
+            if (one(s, rc, rn)) break;
+            if (s == 0 || one(s - 1, rn, rc)) break;
+        }
+    }
+    __syncthreads();
+    tet_flush(p, s_key, s_val, tid, dL_dvcolor, dL_dfopacity);
 }
 
 static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImageState img) {
@@ -546,10 +772,11 @@ static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImag
 size_t tet_facerec_bytes() { return sizeof(TetFaceRec); }
 size_t tet_colrec_bytes() { return sizeof(TetColRec); }
 
-void launch_tet_prep(const dmr_scene& s, TetImageState img, hipStream_t st) {
+void launch_tet_prep(const dmr_scene& s, TetImageState img, uint32_t seq_steps, unsigned long long seq_offset, hipStream_t st) {
     k_tet_prep_faces<<<dim3((unsigned)std::max(1, (s.F + 255) / 256)), dim3(256), 0, st>>>(
         s.F, s.verts, s.faces, s.verts_color, s.faces_opacity, s.face_tets,
-        reinterpret_cast<TetFaceRec*>(img.facerec), reinterpret_cast<TetColRec*>(img.colrec), s.ray_random_seed, img.seed);
+        reinterpret_cast<TetFaceRec*>(img.facerec), reinterpret_cast<TetColRec*>(img.colrec), s.ray_random_seed, img.seed,
+        img.seq, seq_steps, seq_offset);
     if (s.T > 0)
         k_tet_prep_tets<<<dim3((unsigned)((s.T + 255) / 256)), dim3(256), 0, st>>>(
             s.T, s.F, s.verts, s.tets, s.tet_faces, reinterpret_cast<const TetFaceRec*>(img.facerec),
@@ -590,10 +817,11 @@ void launch_tet_zero_grads(float* dL_dvcolor, int64_t n_vcolor, float* dL_dfopac
 
 void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, TetImageState img,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dvcolor, float* dL_dfopacity,
-                         hipStream_t st) {
+                         uint32_t* host_seq_steps, hipStream_t st) {
     if (r1 <= r0) return;
     TetParams p = make_params(s, gx, gy, r0, img);
     StageScope t(DMR_STAGE_TET_BACKWARD, st);
+    k_tet_backward_seq<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, host_seq_steps);
     k_tet_backward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity);
 }
 

@@ -137,7 +137,7 @@ int dmr_invert_mats(const float* in, int count, int transposed, float* out, void
  * name: "image" (f32 [B*P,2]) "ndc_z" (f32 [B*P]) "key_depth" (f32 [B*F]) "max_depth" (tet, f32 [B*F])
  * "tiles_touched" (u32 [B*F]) "ranges" (u32 [B*Nt,2]) "face_list" (u32 [R]) "final_T" "final_prev_T"
  * (f32 [B*W*H]) "n_contrib" (u32 [B*W*H]) "tile_hits" (tri, u32 [B*Nt]: blended (pixel, face) pairs per tile) "first_face" "first_tet" "last_face" "last_tet" (i32, tet)
- * "is_active" (u8, tet).  dst is a DEVICE pointer with room for `cap` bytes.  Returns the byte size
+ * "is_active" (u8, tet) "tet_seq" (tet, u32 [2]: the longest march in steps, the steps per pixel the forward's march sequence had room for).  dst is a DEVICE pointer with room for `cap` bytes.  Returns the byte size
  * of the item (copying min(size, cap) when dst != NULL), or -1. */
 int64_t dmr_export(const dmr_scene* scene, int is_tet, int num_rendered, const char* name,
                    const void* point_buf, const void* face_buf, const void* binning_buf,

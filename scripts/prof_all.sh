@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -- $B --st
 cp $OUT/trace_$c/*/*_kernel_stats.csv $OUT/kernel_stats_$c.csv
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc1_$c -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc1_$c.err || true
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc2_$c -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc2_$c.err || true
+# lane utilisation: active VALU threads per issued VALU instruction = gfx950's derived VALUUtilization
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc3_$c -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc3_$c.err || true
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcf_$c -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/fetch_$c.err || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcw_$c -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/write_$c.err || true
 python3 - "$OUT" "$c" <<'PY'
@@ -29,15 +31,22 @@ def load(d):
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {n: sum(v) / len(v) for n, v in d.items()} for k, d in agg.items()}
 pmc = collections.defaultdict(dict)
-for d in (f"pmc1_{c}", f"pmc2_{c}"):
+for d in (f"pmc1_{c}", f"pmc2_{c}", f"pmc3_{c}"):
     for k, v in load(d).items():
+        if d.startswith("pmc3"):  # the third pass: only what the first two do not hold
+            v = {n: x for n, x in v.items() if n == "SQ_THREAD_CYCLES_VALU"} | {"SQ_ACTIVE_INST_VALU_pass3": v.get("SQ_ACTIVE_INST_VALU", 0.0)}
         pmc[k].update(v)
+for k, v in pmc.items():  # VALUUtilization (counter_defs.yaml): thread-cycles / (instruction-cycles x 64), both from the same pass
+    if v.get("SQ_THREAD_CYCLES_VALU") and v.get("SQ_ACTIVE_INST_VALU_pass3"):
+        v["valu_lane_util"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU_pass3"] * 64.0)
 json.dump(pmc, open(f"{out}/pmc_{c}.json", "w"), indent=1, sort_keys=True)
 with open(f"{out}/pmc_summary_{c}.txt", "w") as f:
     for k, v in sorted(pmc.items()):
         f.write(k.ljust(30) + " " + str({n: round(x / 1e6, 2) for n, x in sorted(v.items())}) + " (x1e6)\n")
         if v.get("SQ_WAVE_CYCLES"):
             f.write(" " * 31 + f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {v.get('SQ_WAIT_ANY', 0) / v['SQ_WAVE_CYCLES']:.3f}\n")
+        if v.get("valu_lane_util"):
+            f.write(" " * 31 + f"VALU lane utilisation (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU) = {v['valu_lane_util']:.3f}\n")
 tr = collections.defaultdict(dict)
 for name, d in (("fetch", f"pmcf_{c}"), ("write", f"pmcw_{c}")):
     for k, v in load(d).items():

@@ -79,6 +79,76 @@ def test_backward(oracle, hip_device, case):
         assert e <= GRAD_TOL, f"{key}: {e}"
 
 
+def _seq_state(_C, args, bufs, H, W):
+    """(longest march of the forward in steps, steps per pixel its march sequence had room for)"""
+    longest, cap = _C.export("tet_seq", args, True, 0, bufs, H, W, th.int32).cpu().numpy().view(np.uint32)[:2]
+    return int(longest), int(cap)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_backward_on_the_march_sequence(oracle, hip_device, case):
+    """The backward of the SECOND call of a view configuration consumes the faces the forward marched through (its
+    sequence fits the capacity the first call's backward reported) instead of re-marching like the reference
+    (cuda_renderer/backward.cu:372-476): same gradients, and they repeat bit for bit from one forward."""
+    from dmesh_renderer_amd import _C
+    d, B, H, W = _scene(case)
+    W = W + 16 * (1 + list(CASES).index(case))  # a view configuration no other test uses: the first call has no estimate
+    d = scenes.kuhn_tets(CASES[case][0], B, H, W, seed=0, opacity=CASES[case][4])
+    if case == "opaque":
+        d["faces_opacity"][::7] = 1.0
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    _, _, _, ost = oracle.tet_forward(sc)
+    gc, gd = upstream_grads(B, H, W)
+    og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+    args = c_args(d, hip_device, tet=True)
+    grads = []
+    for call in range(3):
+        out = _C.render_tets(*args, H, W, 0)
+        g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *out[3:7])
+        th.cuda.synchronize()
+        longest, cap = _seq_state(_C, args, out[3:7], H, W)
+        assert longest == int(ost.get("n_contrib").max())
+        if call == 0:
+            assert cap == 0, "first call of a view configuration: no estimate, the backward re-marches"
+        else:
+            assert 0 < longest <= cap, (longest, cap)  # the sequence is complete: k_tet_backward_seq did the work
+        for got, key in zip(g, ("verts_color", "faces_opacity")):
+            e = rel_err(got.cpu().numpy(), og[key])
+            assert e <= GRAD_TOL, f"call {call} {key}: {e}"
+        grads.append([x.cpu().numpy() for x in g])
+    # sequence path vs re-march path: the same (pixel, face) values, summed in a different order
+    for a, b_ in zip(grads[0], grads[1]):
+        assert rel_err(a, b_) <= 1e-5
+    # the topology the forward reports is unchanged by the sequence stores
+    np.testing.assert_array_equal(_C.export("n_contrib", args, True, 0, out[3:7], H, W, th.int32).cpu().numpy().view(np.uint32), ost.get("n_contrib"))
+
+
+def test_march_sequence_overflow_falls_back(oracle, hip_device):
+    """A scene that outgrows the sequence capacity estimated from the previous call (the same view configuration, first a
+    mesh that covers a corner of the image, then one that fills it): the forward's sequence is incomplete, the device-side
+    check hands the backward to the re-marching kernel, and the gradients are still the oracle's."""
+    from dmesh_renderer_amd import _C
+    B, H, W = 1, 208, 304
+    gc, gd = upstream_grads(B, H, W)
+    seen = []
+    for m, scale in ((3, 0.15), (3, 0.15), (7, 1.0), (7, 1.0)):
+        d = scenes.kuhn_tets(m, B, H, W, seed=0, opacity=(0.02, 0.2))
+        d["verts"] = d["verts"] * scale
+        sc = oracle.scene_from_module_inputs(d, H, W)
+        _, _, _, ost = oracle.tet_forward(sc)
+        og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+        args = c_args(d, hip_device, tet=True)
+        out = _C.render_tets(*args, H, W, 0)
+        g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *out[3:7])
+        th.cuda.synchronize()
+        seen.append(_seq_state(_C, args, out[3:7], H, W))
+        for got, key in zip(g, ("verts_color", "faces_opacity")):
+            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (m, key)
+    assert seen[0][1] == 0 and 0 < seen[1][0] <= seen[1][1], seen   # no estimate, then a complete sequence
+    assert seen[2][0] > seen[2][1] > 0, seen                         # the big mesh after the small one: overflow -> re-march
+    assert 0 < seen[3][0] <= seen[3][1], seen                        # ... and the estimate has caught up
+
+
 def test_module_autograd(oracle, hip_device):
     import dmesh_renderer_amd as dmr
     d, B, H, W = _scene("small")
