@@ -415,6 +415,37 @@ struct TetAccum {
     }
 };
 
+// Arithmetic of k_tet_backward_seq that decides nothing (no index, no branch of the march depends on it): contracted to FMA,
+// 1-ulp reciprocals and the hardware exponential.  Gradients are checked to 1e-4; the forward and the re-marching kernel,
+// whose tests pick faces, keep the exact forms.
+#pragma clang fp contract(fast)
+namespace tfast {
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(float b, F3 a) { return {b * a.x, b * a.y, b * a.z}; }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// (t, u, v) of cuda_renderer/auxiliary.h:265-296 without the hit test (the march already decided)
+__device__ __forceinline__ void tuv(F3 o, F3 d, F3 p0, F3 p1, F3 p2, float& t, float& u, float& v) {
+    const F3 T = o - p0, E1 = p1 - p0, E2 = p2 - p0;
+    const F3 P = cross(d, E2), Q = cross(T, E1);
+    const float inv = rcp(dot(P, E1));
+    t = dot(Q, E2) * inv; u = dot(P, T) * inv; v = dot(Q, d) * inv;
+}
+// ndc depth of a world point: rows z and w of proj * (mv * (pt, 1)) (auxiliary.h:71-90), z / clamp_w(w)
+__device__ __forceinline__ float ndc_depth(F3 pt, const float* __restrict__ mv, const float* __restrict__ pr) {
+    const float vx = mv[0] * pt.x + mv[4] * pt.y + mv[8] * pt.z + mv[12];
+    const float vy = mv[1] * pt.x + mv[5] * pt.y + mv[9] * pt.z + mv[13];
+    const float vz = mv[2] * pt.x + mv[6] * pt.y + mv[10] * pt.z + mv[14];
+    const float cz = pr[2] * vx + pr[6] * vy + pr[10] * vz + pr[14];
+    const float cw = pr[3] * vx + pr[7] * vy + pr[11] * vz + pr[15];
+    return cz * rcp(clamp_w(cw));
+}
+}  // namespace tfast
+#pragma clang fp contract(off)
+
 // One pixel's state of the reverse walk and the gradient of one marched face (cuda_renderer/backward.cu:236-360),
 // shared by the two backward kernels: k_tet_backward re-marches like the reference, k_tet_backward_seq takes the faces
 // from the forward's march sequence.
@@ -467,6 +498,41 @@ struct TetBwdPixel {
         g[0] = i0 * dc0 * intense; g[1] = i0 * dc1 * intense; g[2] = i0 * dc2 * intense;
         g[3] = i1 * dc0 * intense; g[4] = i1 * dc1 * intense; g[5] = i1 * dc2 * intense;
         g[6] = i2 * dc0 * intense; g[7] = i2 * dc1 * intense; g[8] = i2 * dc2 * intense;
+        g[9] = dop;
+    }
+    // the same with tfast's arithmetic, from the face's records (k_tet_backward_seq)
+    __device__ __forceinline__ void face_grad_fast(V3 ro, V3 rd, const float* __restrict__ mv, const float* __restrict__ pr,
+                                                   float4 f0, float4 f1, float4 f2, float4 cq0, float4 cq1, float4 cq2, float4 cq3,
+                                                   float intense, float (&g)[10], int& v0, int& v1, int& v2) {
+#pragma clang fp contract(fast)
+        using namespace tfast;
+        const F3 o = {ro.x, ro.y, ro.z}, d = {rd.x, rd.y, rd.z};
+        float rt, iu, iv;
+        tuv(o, d, {f0.x, f0.y, f0.z}, {f0.w, f1.x, f1.y}, {f1.z, f1.w, f2.x}, rt, iu, iv);
+        const F3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
+        v0 = __float_as_int(cq2.y); v1 = __float_as_int(cq2.z); v2 = __float_as_int(cq2.w);
+        const float i0 = 1.0f - iu - iv, i1 = iu, i2 = iv;
+        const F3 col = intense * ((i0 * c0) + (i1 * c1) + (i2 * c2));  // Q21
+        const float opacity = cq3.x;
+        const float pdepth = ndc_depth(o + (rt * d), mv, pr);
+        if (!first_iter) prev_log_T = prev_log_T - cq3.y;  // logf(1 - opacity), per face (TetColRec)
+        first_iter = false;
+        const float prev_T = __expf(prev_log_T);
+        float dop = 0.f;
+        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = col.x;
+        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = col.y;
+        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = col.z;
+        ard = last_alpha * last_depth + (1.f - last_alpha) * ard; last_depth = pdepth;
+        dop = (col.x - ar0) * dpc0 + (col.y - ar1) * dpc1 + (col.z - ar2) * dpc2 + (pdepth - ard) * dpd;
+        dop *= prev_T;
+        last_alpha = opacity;
+        const float tail = opacity == 1.0f ? -final_prev_T : -final_T * rcp(1.f - opacity);
+        dop += tail * bg_dot + tail * bd_dot;
+        const float sc = opacity * prev_T * intense;
+        const float dc0 = dpc0 * sc, dc1 = dpc1 * sc, dc2 = dpc2 * sc;
+        g[0] = i0 * dc0; g[1] = i0 * dc1; g[2] = i0 * dc2;
+        g[3] = i1 * dc0; g[4] = i1 * dc1; g[5] = i1 * dc2;
+        g[6] = i2 * dc0; g[7] = i2 * dc1; g[8] = i2 * dc2;
         g[9] = dop;
     }
 };
@@ -654,8 +720,8 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
 
 // The backward on the forward's march sequence (dmr_kernels.hpp): a wave walks its rows from the back, step s of all its
 // pixels in the same iteration (a pixel joins at its own last step), one contiguous kilobyte per four steps.  Per step and
-// pixel: ONE ray-triangle evaluation for (t, u, v) -- the same function on the same operands as the reference's reverse
-// march computes for the face it picked, so the values are the same bits -- instead of the tet record, three candidate
+// pixel: ONE ray-triangle evaluation for (t, u, v) -- the function the reference's reverse march evaluates for the face it
+// picked, here with contracted arithmetic (tfast: nothing is decided by it) -- instead of the tet record, three candidate
 // records, three tests and the orientation logic.  Stops where the reference stops: behind first_face, or behind an entry
 // whose bit 31 says the reverse march would find two candidates there.
 __global__ void __launch_bounds__(256)
@@ -732,10 +798,8 @@ k_tet_backward_seq(TetParams p, const float* __restrict__ dL_dcolor, const float
             const int face = (int)(e_cur & 0x7fffffffu);
             float g[10];
             int v0 = 0, v1 = 0, v2 = 0;
-            if (act) {
-                V3 tuv = {0, 0, 0};  // (t, u, v): the same function on the same operands as the reverse march evaluates
-                ray_tri_hit(ro, rd, {cur.f0.x, cur.f0.y, cur.f0.z}, {cur.f0.w, cur.f1.x, cur.f1.y}, {cur.f1.z, cur.f1.w, cur.f2.x}, tuv);
-                st.face_grad(ro, rd, mv, pr, tuv.x, tuv.y, tuv.z, cur.c0, cur.c1, cur.c2, cur.c3, cur.intense, g, v0, v1, v2);
+            if (act) {  // (t, u, v) of the ray on this face, then the face's gradient
+                st.face_grad_fast(ro, rd, mv, pr, cur.f0, cur.f1, cur.f2, cur.c0, cur.c1, cur.c2, cur.c3, cur.intense, g, v0, v1, v2);
                 if (face == first_face || (e_cur & 0x80000000u)) done = true;
             }
             tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
