@@ -242,6 +242,12 @@ def max_abs_err(got: np.ndarray, ref: np.ndarray) -> float:
 SUM_ORDER_TOL = 5e-5
 
 
+def sum_order_tol(name: str) -> float:
+    """The tolerance between two evaluations that differ in summation order only, per gradient tensor:
+    SUM_ORDER_TOL is dL_dverts' (the ray-moment sums), the other four tensors repeat to ~1e-7 and keep 1e-5."""
+    return SUM_ORDER_TOL if name == "verts" else 1e-5
+
+
 def elementwise_close(got: np.ndarray, ref: np.ndarray, rtol: float = 1e-3, atol_scale: float = 2e-5) -> bool:
     """Per entry: |got - ref| <= atol + rtol * |ref| with atol = atol_scale * max(1, max-abs(ref)).  A gradient entry is
     a sum of many signed per-pixel terms (float atomics in the reference, table sums here), so its absolute error

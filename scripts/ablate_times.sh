@@ -4,6 +4,6 @@ mkdir -p $OUT
 export DMR_LIBRARY=$GRAFT_REPO_ROOT/dmesh_renderer_amd/libdmesh_renderer_hip_ablation.so
 for a in "$@"; do
   echo "ABLATE=$a" >> $OUT/ablate.txt
-  DMR_ABLATE=$a python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-early-out 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['stages_ms'])" >> $OUT/ablate.txt || exit 1
+  DMR_ABLATE=$a python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-early-out --no-tet 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['stages_ms'])" >> $OUT/ablate.txt || exit 1
 done
 cat $OUT/ablate.txt

@@ -9,7 +9,7 @@ mkdir -p $OUT
 c=$(echo $CFG | tr A-Z a-z)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-B="python3 bench.py --config $CFG --no-cpu-baseline --no-early-out $*"
+B="python3 bench.py --config $CFG --no-cpu-baseline --no-early-out --no-tet $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -- $B --steps 30 --warmup 5 > $OUT/bench_trace_$c.json 2> $OUT/trace_$c.err || true
 cp $OUT/trace_$c/*/*_kernel_stats.csv $OUT/kernel_stats_$c.csv
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc1_$c -- $B --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc1_$c.err || true

@@ -4,8 +4,8 @@ OUT=gpurun_out/$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-early-out > /dev/null 2> $OUT/fetch.err || true
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-early-out > /dev/null 2> $OUT/write.err || true
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-early-out --no-tet > /dev/null 2> $OUT/fetch.err || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-early-out --no-tet > /dev/null 2> $OUT/write.err || true
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
 out = sys.argv[1]

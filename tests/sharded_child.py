@@ -41,7 +41,7 @@ for assemble in (True, False):
         assert th.equal(c[:, :, 16 * r0:16 * r1], full[0][:, :, 16 * r0:16 * r1]), "band rows differ"
     for a, b, k in zip(g, full[2], names):
         e = scenes.rel_err(a.cpu().numpy(), b.cpu().numpy())
-        assert e <= scenes.SUM_ORDER_TOL, (k, e)
+        assert e <= scenes.sum_order_tol(k), (k, e)
 
 # the tet renderer, same sharding (ShardedTetRenderer: bands, one all-gather of the images, ONE all-reduce over [3P | F])
 Ht = Wt = 160

@@ -172,3 +172,77 @@ def test_async_calls_never_wait_and_flag_overflow(hip_device, oracle):
     finally:
         _C.set_async(False)
         _C.overflowed()
+
+
+@pytest.mark.parametrize("size", [(1, 264, 344), (1, 1456, 1552)])   # 374 tiles: regions laid out by the per-pixel kernel; 8 827: by k_scan_hits
+def test_async_backward_overflow_is_flagged(hip_device, oracle, size):
+    """The backward's own size -- the hit records -- outgrows its estimate while R does not: the same geometry,
+    first with opacities around 0.9 (pixels terminate after a few faces: few records), then asynchronously with opacities
+    around 0.02 (every covered pair is blended: far more than + 25 %).  The records beyond the capacity are dropped on the
+    device (clamped stores, skipped tiles), so the flag MUST be raised, and the following default call must repair it."""
+    from dmesh_renderer_amd import _C
+    dev = hip_device
+    B, H, W = size
+    few = scenes.layered_sheets(12, 24, B, H, W, seed=6, opacity=(0.85, 0.95))
+    many = dict(few)
+    many["faces_opacity"] = th.full_like(few["faces_opacity"], 0.02)
+    gc, gd = upstream_grads(B, H, W)
+    gcd, gdd = gc.to(dev), gd.to(dev)
+    fargs, margs = c_args(few, dev), c_args(many, dev)
+    _C.overflowed()
+    try:
+        o = _C.render_tris(*fargs, H, W)            # default calls: exact sizes, leave both estimates
+        _C.render_tris_backward(*fargs, gcd, gdd, o[0], *o[3:7])
+        hits_few = int(_C.export("tile_hits", fargs, False, o[0], o[3:7], H, W, th.int32).long().sum().item())
+        _C.set_async(True)
+        o = _C.render_tris(*margs, H, W)            # the same lists: R fits its estimate
+        th.cuda.synchronize()
+        assert not _C.overflowed()
+        hits_many = int(_C.export("tile_hits", margs, False, o[0], o[3:7], H, W, th.int32).long().sum().item())
+        assert hits_many > 2 * hits_few
+        _C.render_tris_backward(*margs, gcd, gdd, o[0], *o[3:7])
+        th.cuda.synchronize()
+        assert _C.overflowed(), "the record buffer overflowed: an asynchronous backward must say so"
+        _C.set_async(False)
+        o = _C.render_tris(*margs, H, W)
+        g = _C.render_tris_backward(*margs, gcd, gdd, o[0], *o[3:7])
+        oc, od, og = _oracle_tri(oracle, many, H, W, gc, gd)
+        assert np.abs(o[1].cpu().numpy() - oc).max() <= FWD_TOL
+        for a, k in zip(g, TRI_NAMES):
+            assert rel_err(a.cpu().numpy(), og[k]) <= GRAD_TOL, k
+        assert not _C.overflowed()
+    finally:
+        _C.set_async(False)
+        _C.overflowed()
+
+
+def test_capture_on_an_empty_band(hip_device):
+    """A rank without tile rows (rows = (gy, gy)), or a mesh that is off screen during the warm-up: the default backward
+    short-circuits, and must still leave the estimate a captured / asynchronous backward of the same view configuration
+    asks for (it failed for good with 'without a size estimate').  The captured step's gradients are zero."""
+    from dmesh_renderer_amd import _C
+    dev = hip_device
+    B, H, W = 1, 248, 296
+    gy = (H + 15) // 16
+    d = scenes.layered_sheets(3, 10, B, H, W, seed=8)
+    args = c_args(d, dev)
+    gc, gd = upstream_grads(B, H, W)
+    gcd, gdd = gc.to(dev), gd.to(dev)
+    rows = (gy, gy)
+    s = th.cuda.Stream()
+    s.wait_stream(th.cuda.current_stream())
+    with th.cuda.stream(s):
+        o = _C.render_tris(*args, H, W, rows=rows)   # warm-up, default calls
+        assert o[0] == 0
+        _C.render_tris_backward(*args, gcd, gdd, o[0], *o[3:7], rows=rows)
+    th.cuda.current_stream().wait_stream(s)
+    _C.overflowed()
+    g = th.cuda.CUDAGraph()
+    with th.cuda.graph(g):
+        o = _C.render_tris(*args, H, W, rows=rows)
+        grads = _C.render_tris_backward(*args, gcd, gdd, o[0], *o[3:7], rows=rows)
+    for _ in range(2):
+        g.replay()
+    th.cuda.synchronize()
+    assert not _C.overflowed()
+    assert all(float(t.abs().sum()) == 0.0 for t in grads)

@@ -10,18 +10,11 @@ from dmesh_renderer_amd import _C, scenes
 from dmesh_renderer_amd.scenes import c_args, upstream_grads
 from oracle import oracle as O
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_fuzz_gpu import big_case
 seed = int(sys.argv[1]); dev = th.device("cuda:0"); O.build()
-rng = np.random.RandomState(seed)
-B = int(rng.randint(1, 4)); H = int(rng.randint(17, 260)); W = int(rng.randint(17, 300))
-rng.rand()  # (the campaign's tet draw)
-rows = (0, 0)
-H = int(rng.randint(200, 1600)); W = int(rng.randint(200, 1600))
-if rng.rand() < 0.4:
-    gy = (H + 15) // 16; r0 = int(rng.randint(0, gy)); rows = (r0, int(rng.randint(r0 + 1, gy + 1)))
+d, B, H, W, rows = big_case(seed)
 gc, gd = upstream_grads(B, H, W)
-L = int(rng.randint(1, 13)); n = int(rng.randint(20, 131))
-d = scenes.layered_sheets(L, n, B, H, W, seed=seed, opacity=(0.05, float(rng.uniform(0.2, 0.95))))
-if rng.rand() < 0.5: d["verts"] = d["verts"] * float(rng.uniform(0.3, 3.0))
 sc = O.scene_from_module_inputs(d, H, W, rows=rows)
 oc, od, ost = O.tri_forward(sc)
 g32 = O.tri_backward(sc, ost, gc.numpy(), gd.numpy())["verts"].astype(np.float64)
