@@ -484,6 +484,8 @@ def main():
                                         + (f", opacity U({a.opacity})" if a.opacity else ""),
                             "renderer": cfg.kind, "triangles": F, "verts": P, "image": [H, W], "num_rendered": int(R_full),
                             "host_sync": host_sync,
+                            # what the ONE gradient all-reduce of an N-rank run carries: [3P | 3P | F | B*P | B*F] fp32 (tet: [3P | F])
+                            "allreduce_payload_bytes": int(flat.numel() * 4),
                             "parallelism": (f"EMULATED rank {emu[0]} of {emu[1]}: its tile-row band {rows}, no collective" if emu else
                                             "single GPU" if world == 1 else f"tile-row bands x{world} + 1 RCCL all-reduce")}, **stats),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stages, "early_out": early,

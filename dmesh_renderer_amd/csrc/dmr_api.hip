@@ -86,7 +86,7 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
     s.scan_tmp = c.take<uint32_t>(dmr::scan_tmp_words((int)ntiles));
     s.hit_offset = c.take<uint32_t>(ntiles + 1); s.tile_used = c.take<uint32_t>(ntiles); s.hit_total = c.take<unsigned long long>(1);
     s.tile_offset = c.take<uint32_t>(ntiles + 1);
-    s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(2);  // {R, busy tiles}
+    s.tile_cursor = c.take<uint32_t>(ntiles); s.num_rendered = c.take<int>(1);
     s.tile_order = c.take<uint32_t>(ntiles);
     s.final_T = c.take<float>(npix); s.final_prev_T = c.take<float>(npix); s.n_contrib = c.take<uint32_t>(npix);
     if (tet) {
@@ -418,7 +418,7 @@ int dmr_tri_forward(const dmr_scene* s, float* out_color, float* out_depth, dmr_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PointState ps; FaceState fs; ImageState is;
     auto render = [&](const BinningState& bs) {
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.tile_bound, is.hit_offset, is.tile_used, is.tile_order, is.num_rendered + 1, is.mask_offset};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.tile_bound, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
         const dmr_scene sc = canonical(s, is.mats);
         dmr::launch_tri_forward(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, d.ntiles > dmr::SCAN_SINGLE_MAX ? nullptr : bs.keys,
                                 bs.face_list, bs.capacity, img, out_color,
@@ -478,7 +478,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         float* frow = reinterpret_cast<float*>(work + vbytes);
         float4* pixrec = reinterpret_cast<float4*>(work + vbytes + fbytes);
         dmr::HitRecord* hits = reinterpret_cast<dmr::HitRecord*>(work + vbytes + fbytes + pbytes);
-        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.tile_bound, is.hit_offset, is.tile_used, is.tile_order, is.num_rendered + 1, is.mask_offset};
+        dmr::TriImageState img{is.final_T, is.final_prev_T, is.n_contrib, is.tile_hits, is.tile_bound, is.hit_offset, is.tile_used, is.tile_order, is.mask_offset};
         const dmr_scene sc = canonical(s, is.mats);
         // (Splitting the tiles into bands whose hit-parallel kernel runs on a second stream while the next band's
         // per-pixel kernel computes -- atomic unit and SIMDs busy at the same time -- was measured and lost: 0.56 ms

@@ -413,8 +413,7 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
     // exclusive scan of the cells (bucket-major): bucket 0 holds the longest lists, empty tiles come last
     const uint32_t cell_base = block_exclusive_scan(bucket[tid], tid, wave_sum);
     bucket[tid] = cell_base;
-    const uint32_t nbusy = wave_sum[16];  // tiles with a non-empty list: the first nbusy entries of tile_order
-    if (tid == 0) bucket[ORDER_CELLS] = nbusy;
+    if (tid == 0) bucket[ORDER_CELLS] = wave_sum[16];
 #pragma unroll
     for (int j = 0; j < SCAN_BATCH; j++) {
         const int i = j * 1024 + tid;
@@ -440,7 +439,7 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
     for (int j = 0; j < SCAN_BATCH; j++) { const int i = j * 1024 + tid; if (i < n) tile_order[i] = slab[i]; }
     // host_num_rendered: pinned host memory, read by the host after the event recorded behind this kernel
     if (tid == 0) {
-        tile_offset[n] = total; num_rendered[0] = (int)total; num_rendered[1] = (int)nbusy;
+        tile_offset[n] = total; *num_rendered = (int)total;
         if (host_num_rendered) *host_num_rendered = (int)total;
         if (overflow && total > capacity) *overflow = 1u;  // asynchronous call that outgrew its buffer (sticky, pinned host memory)
     }
@@ -524,10 +523,7 @@ k_scan_tiles_blocks(int nblk, int n, uint32_t* __restrict__ blk_sum, uint32_t* _
             if (lane >= d) bi += o;
         }
         if (tid < ORDER_BUCKETS) bucket_count[tid] = bi - c;
-        if (tid == ORDER_BUCKETS - 1) {
-            bucket_count[ORDER_BUCKETS] = bi;
-            if (num_rendered) num_rendered[1] = (int)bi;  // tiles with a non-empty list: the first entries of tile_order
-        }
+        if (tid == ORDER_BUCKETS - 1) bucket_count[ORDER_BUCKETS] = bi;
     }
 }
 

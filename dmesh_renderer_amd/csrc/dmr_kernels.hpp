@@ -57,7 +57,6 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
 // scan_tmp: scan_tmp_words(ntiles) u32 of scratch whose first SCAN_TMP_BUCKETS words are zero on entry
 constexpr int SCAN_TMP_BUCKETS = 128;
 size_t scan_tmp_words(int ntiles);
-// num_rendered: int[2] = {R, number of tiles with a non-empty list = how many entries of tile_order are busy tiles}.
 // host_num_rendered (pinned, may be null): receives R.  overflow (pinned, may be null): set to 1 when R > capacity
 // (asynchronous calls, which never read R on the host)
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
@@ -80,7 +79,6 @@ struct TriImageState {
     const uint32_t* hit_offset;     // record regions: exclusive scan of the tiles' record bounds (k_scan_hits, backward)
     uint32_t* tile_used;            // records k_tri_backward_pix wrote into a tile's region (padded runs; <= the bound)
     const uint32_t* tile_order;  // all B * gx * gy tiles, longest list first (k_scan_tiles)
-    const int* num_busy;         // how many of them have a non-empty list (the first entries of tile_order)
     // Coverage masks the forward keeps for the backward: one 4 KB slot (256 pixels x 128 face bits) per 128-entry chunk of a
     // tile's list, slot = list offset / 128 + tile index.  They live in the binning buffer behind the lists, whose capacity
     // the backward does not know on the host (speculative sizing): the byte offset is kept on the device.

@@ -97,7 +97,6 @@ struct TriParams {
     unsigned long long* keys;  // (depth_bits << 32 | face) of every list entry, unsorted: the forward sorts its tile's
     float* final_T; float* final_prev_T; uint32_t* n_contrib;
     uint32_t* tile_hits; uint32_t* tile_bound; const uint32_t* hit_offset; uint32_t* tile_used; const uint32_t* tile_order;
-    const int* num_busy;  // entries of tile_order that are tiles with a non-empty list (k_scan_tiles)
     const unsigned long long* mask_offset;  // coverage masks: byte offset behind face_list (TriImageState)
 };
 
@@ -507,53 +506,32 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         const uint32_t z0 = min(work_floats, blockIdx.x * per), z1 = min(work_floats, z0 + per);
         for (uint32_t i = z0 + tid; i < z1; i += 256) work[i] = 0.f;
     }
-    const bool self = !SCANNED && regions.hit_offset != nullptr;
-    if (self && blockIdx.x == gridDim.x - 1) {
-        // The total of the record bounds (sizes the next call's record buffer; says whether this one overflowed): left by the
-        // launch's last workgroup -- its own tile, if it has one at all, is among the shortest.
-        static_assert(SCAN_SINGLE_MAX == 8 * 256 * 4, "eight 16-byte loads per thread cover every tile");
-        const int ntiles_all = p.B * p.gx * p.gy;
-        const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(p.tile_bound);
-        unsigned long long sum = 0ull;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int q = 256 * j + tid, i = 4 * q;
-            if (i < ntiles_all) {  // (a last partial quad reads into the next array of the buffer)
-                const uint4 v = tb[q];
-                sum += (unsigned long long)v.x + (i + 1 < ntiles_all ? v.y : 0u);
-                sum += (unsigned long long)(i + 2 < ntiles_all ? v.z : 0u) + (i + 3 < ntiles_all ? v.w : 0u);
-            }
-        }
-#pragma unroll
-        for (int dlt = 32; dlt > 0; dlt >>= 1) sum += __shfl_xor(sum, dlt, 64);
-        if (lane == 0) s_before[wave] = sum;
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned long long total = s_before[0] + s_before[1] + s_before[2] + s_before[3];
-            *regions.hit_total = total;
-            if (regions.host_hit_total) *regions.host_hit_total = total;
-            if (regions.overflow && total > (unsigned long long)capacity) *regions.overflow = 1u;
-        }
-        __syncthreads();  // (s_before is reused below)
-    }
-    // Tiles are taken longest list first (tile_order, k_scan_tiles); only its first *num_busy entries are tiles with a list
-    // at all -- 5 244 of C4's 8 160 workgroups leave here, behind one scalar load (they used to find out through three
-    // dependent loads: order -> offsets -> bound; -4 us).  A tile outside this shard's band has an empty list too.
-    if ((int)blockIdx.x >= *p.num_busy) return;  // uniform
+    // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
     const int tile = (int)p.tile_order[blockIdx.x];
     const int tx = tile % p.gx, ty = (tile / p.gx) % p.gy, b = tile / (p.gx * p.gy);
     const uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
     // The tile's region of the record buffer.  Without a scan kernel (regions.hit_offset, dmr_kernels.hpp) it starts at the
-    // sum of the bounds of all tiles before this one -- an empty tile has none -- and this workgroup publishes offset and use
-    // of its tile for the hit-parallel kernel (every busy tile has exactly one workgroup here).
+    // sum of the bounds of all tiles before this one -- an empty tile, or one outside this shard's band, has none -- and this
+    // workgroup publishes offset and use of its tile for the hit-parallel kernel (every tile has exactly one workgroup here).
     uint32_t region0 = 0u;
     unsigned long long before = 0ull;  // (this thread's part of) the bounds of the tiles before this one
+    const bool self = !SCANNED && regions.hit_offset != nullptr, last = tile == p.B * p.gx * p.gy - 1;
+    uint32_t my_bound = 0u;
     if (self) {
-        const uint32_t bound = p.tile_bound[tile];
-        if (bound == 0u) {  // uniform: nothing blended in this tile
+        static_assert(SCAN_SINGLE_MAX == 8 * 256 * 4, "eight 16-byte loads per thread cover every tile");
+        const uint32_t bound = my_bound = p.tile_bound[tile];
+        if (bound == 0u && !last) {  // uniform
             if (tid == 0) p.tile_used[tile] = 0u;
             return;
         }
+    } else {
+        if (ty < p.r0 || ty >= p.r1) return;  // uniform
+        if (begin == end) return;  // uniform
+        region0 = p.hit_offset[tile];
+        if (region0 == p.hit_offset[tile + 1]) return;  // no pixel of the tile blended anything
+    }
+    if (self) {
+        const uint32_t bound = my_bound;
         // this thread's part of the bounds of the tiles before this one: eight 16-byte loads, all in flight at once.
         // (Measured at C4, k_tri_backward_pix / step: this form 90 us / 0.320 ms; the same loads consumed behind the pixel's
         // own loads, 32 registers live across the ray set-up, or the pixel's loads requested first: spills at the kernel's
@@ -573,11 +551,20 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
             before += (unsigned long long)((i < tile ? v[j].x : 0u)) + (i + 1 < tile ? v[j].y : 0u);
             before += (unsigned long long)((i + 2 < tile ? v[j].z : 0u)) + (i + 3 < tile ? v[j].w : 0u);
         }
-    } else {
-        if (ty < p.r0 || ty >= p.r1) return;  // uniform
-        if (begin == end) return;  // uniform
-        region0 = p.hit_offset[tile];
-        if (region0 == p.hit_offset[tile + 1]) return;  // no pixel of the tile blended anything
+        if (bound == 0u) {  // the last tile, and nothing blended in it: only the total is wanted of this workgroup
+#pragma unroll
+            for (int dlt = 32; dlt > 0; dlt >>= 1) before += __shfl_xor(before, dlt, 64);
+            if (lane == 0) s_before[wave] = before;
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long total = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+                *regions.hit_total = total;
+                if (regions.host_hit_total) *regions.host_hit_total = total;
+                if (regions.overflow && total > (unsigned long long)capacity) *regions.overflow = 1u;
+                p.tile_used[tile] = 0u;
+            }
+            return;
+        }
     }
     const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
     const int px = tx * TILE + lx, py = ty * TILE + ly;
@@ -628,6 +615,12 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         region0 = (uint32_t)before;  // (offsets beyond 2^32 wrap harmlessly: the total says so)
         if (tid == 0) {
             regions.hit_offset[tile] = region0;
+            if (last) {
+                const unsigned long long all = before + p.tile_bound[tile];
+                *regions.hit_total = all;
+                if (regions.host_hit_total) *regions.host_hit_total = all;
+                if (regions.overflow && all > (unsigned long long)capacity) *regions.overflow = 1u;
+            }
             if (total == 0) p.tile_used[tile] = 0u;  // (cannot happen for a tile with blended pairs; published all the same)
         }
     }
@@ -936,10 +929,9 @@ __device__ __forceinline__ void tab_find3(uint32_t* __restrict__ key, const uint
 __global__ void __launch_bounds__(256, DMR_HITS_WAVES)
 k_tri_backward_hits(TriParams p, const float4* __restrict__ pixrec, const HitRecord* __restrict__ hits, uint32_t capacity,
                     float* __restrict__ vrow, float* __restrict__ frow) {
-    if ((int)blockIdx.x >= *p.num_busy) return;  // uniform: the tiles behind have empty lists (their tile_used is not defined)
     const int tile = (int)p.tile_order[blockIdx.x];
     uint32_t nrec = p.tile_used[tile];
-    if (nrec == 0u) return;  // uniform: nothing blended in this tile
+    if (nrec == 0u) return;  // uniform: nothing blended in this tile (or outside this shard's band)
     const uint32_t rec0 = p.hit_offset[tile];
     // (fewer only while a size guess is being refuted / an asynchronous call overflowed: whole groups inside the buffer)
     if (rec0 + ((nrec + (uint32_t)(HIT_BLOCK - 1)) & ~(uint32_t)(HIT_BLOCK - 1)) > capacity) return;  // the results are thrown away
@@ -1261,7 +1253,7 @@ static TriParams make_params(const dmr_scene& s, int gx, int gy, int r0, int r1,
     p.inv_mv = s.inv_mv_mats; p.inv_proj = s.inv_proj_mats; p.faces_intense = s.faces_intense; p.bg = s.background;
     p.vproj = vproj; p.tile_offset = tile_offset; p.face_list = face_list; p.keys = nullptr;
     p.final_T = img.final_T; p.final_prev_T = img.final_prev_T; p.n_contrib = img.n_contrib;
-    p.tile_hits = img.tile_hits; p.tile_bound = img.tile_bound; p.hit_offset = img.hit_offset; p.tile_used = img.tile_used; p.tile_order = img.tile_order; p.num_busy = img.num_busy;
+    p.tile_hits = img.tile_hits; p.tile_bound = img.tile_bound; p.hit_offset = img.hit_offset; p.tile_used = img.tile_used; p.tile_order = img.tile_order;
     p.mask_offset = img.mask_offset;
     p.list_capacity = 0xffffffffu;
     return p;
@@ -1287,7 +1279,10 @@ void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1,
     // (an empty band never gets here: dmr_tri_backward zeroes the gradients itself -- this kernel is also what zeroes `work`)
     TriParams p = make_params(s, gx, gy, r0, r1, vproj, tile_offset, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD, st);
-    const dim3 grid((unsigned)(s.B * gx * gy)), block(256);
+    dim3 grid((unsigned)(s.B * gx * gy)), block(256);
+#ifdef DMR_ABLATION
+    if (DMR_DBG(p, 131072)) grid.x = std::min(grid.x, 3072u);  // timing experiment (results invalid): only the busiest tiles' workgroups
+#endif
     if (regions.hit_offset)
         k_tri_backward_pix<false><<<grid, block, 0, st>>>(p, dL_dcolor, dL_ddepth, pixrec, hits, capacity, work, (uint32_t)work_floats, regions);
     else
@@ -1300,7 +1295,11 @@ void launch_tri_backward_hits(const dmr_scene& s, int gx, int gy, const float4* 
     if (capacity == 0) return;
     TriParams p = make_params(s, gx, gy, 0, 0, vproj, nullptr, face_list, img);
     StageScope t(DMR_STAGE_TRI_BACKWARD_HITS, st);
-    k_tri_backward_hits<<<dim3((unsigned)(s.B * gx * gy)), dim3(256), 0, st>>>(p, pixrec, hits, capacity, vrow, frow);
+    unsigned nblocks = (unsigned)(s.B * gx * gy);
+#ifdef DMR_ABLATION
+    if (DMR_DBG(p, 131072)) nblocks = std::min(nblocks, 3072u);  // timing experiment, as above
+#endif
+    k_tri_backward_hits<<<dim3(nblocks), dim3(256), 0, st>>>(p, pixrec, hits, capacity, vrow, frow);
 }
 
 void launch_tri_unpack(const dmr_scene& s, const float* vrow, const float* frow, float* dL_dverts,

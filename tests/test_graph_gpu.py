@@ -199,7 +199,7 @@ def test_async_backward_overflow_is_flagged(hip_device, oracle, size):
         th.cuda.synchronize()
         assert not _C.overflowed()
         hits_many = int(_C.export("tile_hits", margs, False, o[0], o[3:7], H, W, th.int32).long().sum().item())
-        assert hits_many > 2 * hits_few
+        assert hits_many > 1.5 * hits_few + 8192  # far beyond the + 25 % (+ 4096) the estimate allows for
         _C.render_tris_backward(*margs, gcd, gdd, o[0], *o[3:7])
         th.cuda.synchronize()
         assert _C.overflowed(), "the record buffer overflowed: an asynchronous backward must say so"
