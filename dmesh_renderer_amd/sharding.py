@@ -63,10 +63,17 @@ def balanced_bands(row_work: Sequence[float], world: int) -> List[Tuple[int, int
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
-def row_work_from_ranges(ranges: np.ndarray, B: int, gy: int, gx: int) -> np.ndarray:
-    """Per-tile-row work from the per-tile [start, end) list ranges of one full forward."""
+# What a tile costs besides its list entries, in list entries (its workgroups in the three tile kernels, its pixels' state and
+# images, its share of the scans).  From the per-rank kernel sums of C5 cut eight ways by list entries alone
+# (profiles/r03/shard_kernel_sums_c5.json, first cut: the edge bands, 72 tile rows, took 2.14 ms, the middle band, 19 rows with
+# the same number of entries, 1.64 ms): 0.5 ms per 54 000 tiles against 1.64 ms per 2.34 M entries.
+TILE_COST_ENTRIES = 13.0
+
+
+def row_work_from_ranges(ranges: np.ndarray, B: int, gy: int, gx: int, tile_cost: float = TILE_COST_ENTRIES) -> np.ndarray:
+    """Per-tile-row work from the per-tile [start, end) list ranges of one full forward: list entries + a cost per tile."""
     r = np.asarray(ranges).reshape(B, gy, gx, 2).astype(np.int64)
-    return (r[..., 1] - r[..., 0]).sum(axis=(0, 2))
+    return (r[..., 1] - r[..., 0]).sum(axis=(0, 2)) + tile_cost * B * gx
 
 
 def flatten_grads(grads: Sequence[th.Tensor], out: Optional[th.Tensor] = None) -> th.Tensor:
