@@ -69,10 +69,10 @@ size_t carve_face(void* b, size_t BF, size_t F, size_t T, bool tet, FaceState& s
     s.max_depth = tet ? c.take<float>(BF) : nullptr;
     s.tiles_touched = c.take<uint32_t>(BF);
     s.facerec = s.colrec = s.tetrec = nullptr;
-    if (tet) {  // packed march records
-        s.facerec = c.take<char>(BF * dmr::tet_facerec_bytes());  // per (view, face): they hold the view's ray origin
+    if (tet) {  // packed march records (view independent)
+        s.facerec = c.take<char>(F * dmr::tet_facerec_bytes());
         s.colrec = c.take<char>(F * dmr::tet_colrec_bytes());
-        s.tetrec = c.take<char>(T * dmr::tet_tetrec_bytes());
+        s.tetrec = c.take<int4>(T);
     }
     return c.off;
 }

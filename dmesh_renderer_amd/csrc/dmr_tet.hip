@@ -23,16 +23,11 @@ constexpr int FI_CHUNK = 256;
 struct alignas(16) HitRec { float p0[3], p1[3], p2[3]; float min_depth, max_depth; int face; };
 static_assert(sizeof(HitRec) == 48, "HitRec");
 
-// Per (view, face): the ray-independent part of ray_tri_intersection (cuda_renderer/auxiliary.h:265-296) -- the ray origin is the
-// same for every pixel of a view -- and the unit normal before orientation: one 64-byte line.
-struct alignas(16) TetFaceRec { float T[3], E1[3], E2[3], Q[3]; float tnum; float n[3]; };
+struct alignas(16) TetFaceRec { float p0[3], p1[3], p2[3], n[3]; int ft0, ft1; float opacity; int pad; };
 static_assert(sizeof(TetFaceRec) == 64, "TetFaceRec");
 // log1m = logf(1 - opacity), evaluated once per face by the same device function the march would call per step
 struct alignas(16) TetColRec { float c0[3], c1[3], c2[3]; int v0, v1, v2; float opacity, log1m; int pad[2]; };
 static_assert(sizeof(TetColRec) == 64, "TetColRec");
-// Per tet: its four faces (bit 31: tet_face_outward_normal flips the unit normal) and the tet behind each of them (-1: none).
-struct alignas(16) TetRec { int face[4]; int nbr[4]; };
-static_assert(sizeof(TetRec) == 32, "TetRec");
 
 struct TetParams {
     int B, P, F, W, H, gx, gy, r0;
@@ -44,7 +39,7 @@ struct TetParams {
     const float* faces_intense; const float* bg;
     const int* tets; const int* face_tets; const int* tet_faces;
     const int* seed;  // ray_random_seed of the forward, kept in the image buffer for the backward
-    const TetFaceRec* facerec; const TetColRec* colrec; const TetRec* tetrec;
+    const TetFaceRec* facerec; const TetColRec* colrec; const int4* tetrec;
     TetImageState img;
 };
 
@@ -52,24 +47,18 @@ struct TetParams {
 // Packed march records, rebuilt by every forward call (geometry and colours are inputs) and kept in the
 // face buffer for the backward.  A march step of the reference (cuda_renderer/forward.cu:704-767) is a
 // chain of narrow dependent gathers: tet_faces -> faces -> verts for four faces, tets -> verts for the
-// centre, then four normalised outward normals (sqrt + divide each), and three full ray-triangle tests.
-// Everything that does not depend on the ray DIRECTION is hoisted here, with the reference's arithmetic
-// (the same operations in the same order on the same operands: the same bits), so the decisions stay
-// bit-identical:
-//   TetFaceRec [B][F] : T = o - p0, E1 = p1 - p0, E2 = p2 - p0, Q = T x E1, tnum = Q . E2 (t's numerator) of the
-//                view's ray origin o (the same for all its pixels), and the UNIT normal before orientation.  A test
-//                is then P = d x E2, denom = P . E1, 1 / denom, three products: ~42 instructions instead of ~70.
-//   TetColRec [F] : the three vertex colours and ids, the opacity and logf(1 - opacity)
-//   TetRec [T]    : the four faces of a tet, bit 31 set where tet_face_outward_normal flips the unit normal
-//                (dot(n, centre - p0) > 0, cuda_renderer/auxiliary.h:386-392; dot(-n, d) == -dot(n, d) exactly), and
-//                the tet on the other side of each (the reference's rule: the first entry of face_tets[face] that is
-//                neither this tet nor -1, forward.cu:761-767)
-// A step is then TetRec -> 3 x TetFaceRec: two dependent levels of 16-byte loads.
+// centre, then four normalised outward normals (sqrt + divide each).  Everything that does not depend
+// on the ray is hoisted here, with the reference's arithmetic, so the decisions stay bit-identical:
+//   TetFaceRec : the three vertices, the UNIT normal before orientation, face_tets, opacity -- one 64-byte line
+//   TetColRec  : the three vertex colours and ids, the opacity and logf(1 - opacity) -- one 64-byte line
+//   tetrec     : the four faces of a tet, bit 31 set where tet_face_outward_normal flips the unit normal
+//                (dot(n, centre - p0) > 0, cuda_renderer/auxiliary.h:386-392); dot(-n, d) == -dot(n, d) exactly.
+// A step is then tetrec -> 3 x TetFaceRec: two dependent levels of 16-byte loads.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_tet_prep_faces(int B, int F, const float* __restrict__ verts, const int* __restrict__ faces,
+k_tet_prep_faces(int F, const float* __restrict__ verts, const int* __restrict__ faces,
                  const float* __restrict__ verts_color, const float* __restrict__ faces_opacity,
-                 const float* __restrict__ inv_mv, TetFaceRec* __restrict__ facerec, TetColRec* __restrict__ colrec,
+                 const int* __restrict__ face_tets, TetFaceRec* __restrict__ facerec, TetColRec* __restrict__ colrec,
                  int seed, int* __restrict__ seed_slot, TetSeq* __restrict__ seq, uint32_t seq_steps, unsigned long long seq_offset) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f == 0) {
@@ -79,82 +68,56 @@ k_tet_prep_faces(int B, int F, const float* __restrict__ verts, const int* __res
     if (f >= F) return;
     const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
     const V3 p0 = load_v3(verts, v0), p1 = load_v3(verts, v1), p2 = load_v3(verts, v2);
-    const V3 E1 = p1 - p0, E2 = p2 - p0;
-    V3 n = cross(E1, E2);  // cuda_renderer/auxiliary.h:375-384
+    V3 n = cross(p1 - p0, p2 - p0);  // cuda_renderer/auxiliary.h:375-384
     float n_norm = sqrtf(dot(n, n));
     n_norm = fmaxf(n_norm, 0.0001f);
     n = n / n_norm;
-    for (int b = 0; b < B; b++) {
-        const V3 o = {inv_mv[16 * b + 12], inv_mv[16 * b + 13], inv_mv[16 * b + 14]};  // the view's ray origin (forward.cu:104-106)
-        const V3 T = o - p0;
-        const V3 Q = cross(T, E1);
-        TetFaceRec r;
-        r.T[0] = T.x; r.T[1] = T.y; r.T[2] = T.z;
-        r.E1[0] = E1.x; r.E1[1] = E1.y; r.E1[2] = E1.z;
-        r.E2[0] = E2.x; r.E2[1] = E2.y; r.E2[2] = E2.z;
-        r.Q[0] = Q.x; r.Q[1] = Q.y; r.Q[2] = Q.z;
-        r.tnum = dot(Q, E2);
-        r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
-        facerec[(int64_t)b * F + f] = r;
-    }
+    TetFaceRec r;
+    r.p0[0] = p0.x; r.p0[1] = p0.y; r.p0[2] = p0.z;
+    r.p1[0] = p1.x; r.p1[1] = p1.y; r.p1[2] = p1.z;
+    r.p2[0] = p2.x; r.p2[1] = p2.y; r.p2[2] = p2.z;
+    r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
+    r.ft0 = face_tets[2 * f]; r.ft1 = face_tets[2 * f + 1];
+    r.opacity = faces_opacity[f]; r.pad = 0;
+    facerec[f] = r;
     const V3 c0 = load_v3(verts_color, v0), c1 = load_v3(verts_color, v1), c2 = load_v3(verts_color, v2);
     TetColRec c;
     c.c0[0] = c0.x; c.c0[1] = c0.y; c.c0[2] = c0.z;
     c.c1[0] = c1.x; c.c1[1] = c1.y; c.c1[2] = c1.z;
     c.c2[0] = c2.x; c.c2[1] = c2.y; c.c2[2] = c2.z;
     c.v0 = v0; c.v1 = v1; c.v2 = v2;
-    c.opacity = faces_opacity[f]; c.log1m = logf(1.0f - c.opacity); c.pad[0] = c.pad[1] = 0;
+    c.opacity = r.opacity; c.log1m = logf(1.0f - r.opacity); c.pad[0] = c.pad[1] = 0;
     colrec[f] = c;
 }
 
 __global__ void __launch_bounds__(256)
-k_tet_prep_tets(int T, int F, const float* __restrict__ verts, const int* __restrict__ faces, const int* __restrict__ tets,
-                const int* __restrict__ tet_faces, const int* __restrict__ face_tets, const TetFaceRec* __restrict__ facerec,
-                TetRec* __restrict__ tetrec) {
+k_tet_prep_tets(int T, int F, const float* __restrict__ verts, const int* __restrict__ tets,
+                const int* __restrict__ tet_faces, const TetFaceRec* __restrict__ facerec, int4* __restrict__ tetrec) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const V3 center = tet_center(verts, tets, t);
-    TetRec r;
+    int f[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        int f = tet_faces[4 * t + i];
-        int nbr = -1;
-        if (f >= 0 && f < F) {
-            const TetFaceRec& fr = facerec[f];  // (view 0's record: the normal is the same in all views)
-            const V3 n = {fr.n[0], fr.n[1], fr.n[2]}, p0 = load_v3(verts, faces[3 * f]);
-            const int ft0 = face_tets[2 * f], ft1 = face_tets[2 * f + 1];
-            if (!(ft0 == t || ft0 == -1)) nbr = ft0;
-            else if (!(ft1 == t || ft1 == -1)) nbr = ft1;
-            if (dot(n, center - p0) > 0.0f) f |= (int)0x80000000;
+        f[i] = tet_faces[4 * t + i];
+        if (f[i] >= 0 && f[i] < F) {
+            const TetFaceRec& r = facerec[f[i]];
+            const V3 n = {r.n[0], r.n[1], r.n[2]}, p0 = {r.p0[0], r.p0[1], r.p0[2]};
+            if (dot(n, center - p0) > 0.0f) f[i] |= (int)0x80000000;
         }
-        r.face[i] = f; r.nbr[i] = nbr;
     }
-    tetrec[t] = r;
+    tetrec[t] = make_int4(f[0], f[1], f[2], f[3]);
 }
 
-__device__ __forceinline__ TetFaceRec load_facerec(const TetFaceRec* __restrict__ a, int64_t f) {
+__device__ __forceinline__ TetFaceRec load_facerec(const TetFaceRec* __restrict__ a, int f) {
     const float4* q = reinterpret_cast<const float4*>(a + f);
     const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     TetFaceRec r;
-    r.T[0] = q0.x; r.T[1] = q0.y; r.T[2] = q0.z; r.E1[0] = q0.w;
-    r.E1[1] = q1.x; r.E1[2] = q1.y; r.E2[0] = q1.z; r.E2[1] = q1.w;
-    r.E2[2] = q2.x; r.Q[0] = q2.y; r.Q[1] = q2.z; r.Q[2] = q2.w;
-    r.tnum = q3.x; r.n[0] = q3.y; r.n[1] = q3.z; r.n[2] = q3.w;
+    r.p0[0] = q0.x; r.p0[1] = q0.y; r.p0[2] = q0.z; r.p1[0] = q0.w;
+    r.p1[1] = q1.x; r.p1[2] = q1.y; r.p2[0] = q1.z; r.p2[1] = q1.w;
+    r.p2[2] = q2.x; r.n[0] = q2.y; r.n[1] = q2.z; r.n[2] = q2.w;
+    r.ft0 = __float_as_int(q3.x); r.ft1 = __float_as_int(q3.y); r.opacity = q3.z; r.pad = 0;
     return r;
-}
-
-// ray_tri_intersection (cuda_renderer/auxiliary.h:265-296) on a face's record: the same products in the same order as
-// ray_tri_hit (dmr_device.hpp) evaluates from the vertices, with T, E1, E2, Q and Q . E2 taken from the record
-__device__ __forceinline__ bool hit_rec(V3 d, const TetFaceRec& r, V3& tuv) {
-    const V3 T = {r.T[0], r.T[1], r.T[2]}, E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]}, Q = {r.Q[0], r.Q[1], r.Q[2]};
-    const V3 P = cross(d, E2);
-    const float denom = dot(P, E1);
-    if (denom == 0.0f) return false;
-    const float inv_denom = 1.0f / denom;
-    tuv.x = r.tnum * inv_denom;
-    tuv.y = dot(P, T) * inv_denom;
-    tuv.z = dot(Q, d) * inv_denom;
-    return (tuv.x >= 0.0f && tuv.y >= 0.0f && tuv.z >= 0.0f && tuv.y + tuv.z <= 1.0f);
 }
 
 // dot(outward normal of `face` as seen from `tet`, d): flip = bit 31 of the tet's record entry
@@ -230,11 +193,11 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
     if (!inside) return;
     int ft = -1;
     if (ff >= 0) {
-        const TetFaceRec fr = load_facerec(p.facerec, (int64_t)b * p.F + ff);
+        const TetFaceRec fr = load_facerec(p.facerec, ff);
         for (int i = 0; i < 2; i++) {
-            const int tet_id = p.face_tets[2 * ff + i];
+            const int tet_id = i == 0 ? fr.ft0 : fr.ft1;
             if (tet_id < 0) continue;
-            const int4 tr = *reinterpret_cast<const int4*>(p.tetrec[tet_id].face);
+            const int4 tr = p.tetrec[tet_id];
             const int e[4] = {tr.x, tr.y, tr.z, tr.w};
             bool flip = false;
 #pragma unroll
@@ -247,10 +210,10 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
 }
 
 // (t, u, v) of the ray on `face` and the face's unit normal (carried from step to step by the march)
-__device__ __forceinline__ void face_tuv(const TetParams& p, int b, V3 rd, int face, float& rt, float& iu, float& iv, V3& n) {
+__device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int face, float& rt, float& iu, float& iv, V3& n) {
     V3 tuv = {0, 0, 0};
-    const TetFaceRec r = load_facerec(p.facerec, (int64_t)b * p.F + face);
-    hit_rec(rd, r, tuv);
+    const TetFaceRec r = load_facerec(p.facerec, face);
+    ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]}, {r.p2[0], r.p2[1], r.p2[2]}, tuv);
     rt = tuv.x; iu = tuv.y; iv = tuv.z;
     n = {r.n[0], r.n[1], r.n[2]};
 }
@@ -264,10 +227,9 @@ __device__ __forceinline__ void face_tuv(const TetParams& p, int b, V3 rd, int f
 // always qualifies there (it was accepted as a hit with this ray, and its normal is checked below), so this flag is all the
 // backward needs to know of this tet.
 template <bool FWD>
-__device__ __forceinline__ bool march_step(const TetParams& p, int b, V3 rd, int& curr_face, int& curr_tet,
+__device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet,
                                            float& curr_rt, float& curr_iu, float& curr_iv, V3& curr_n, bool* back_amb = nullptr) {
-    const int4* trp = reinterpret_cast<const int4*>(p.tetrec + curr_tet);
-    const int4 tr = trp[0], nb = trp[1];  // faces (bit 31: orientation) and the tets behind them
+    const int4 tr = p.tetrec[curr_tet];
     // The three faces of the tet other than the current one, in the record's order, with their orientation bits --
     // by selects, not by indexing small arrays (which the compiler put in scratch memory: 12 scratch accesses per step).
     const int t0 = tr.x & 0x7fffffff, t1 = tr.y & 0x7fffffff, t2 = tr.z & 0x7fffffff, t3 = tr.w & 0x7fffffff;
@@ -275,39 +237,43 @@ __device__ __forceinline__ bool march_step(const TetParams& p, int b, V3 rd, int
     if ((int)m0 + (int)m1 + (int)m2 + (int)m3 != 1) return false;  // the reference's `cnt != 3`
     const bool s1 = m0, s2 = m0 || m1, s3 = s2 || m2;  // entry i of `others` is record entry i + (shift i)
     const int r0e = s1 ? tr.y : tr.x, r1e = s2 ? tr.z : tr.y, r2e = s3 ? tr.w : tr.z;
-    const int nb0 = s1 ? nb.y : nb.x, nb1 = s2 ? nb.z : nb.y, nb2 = s3 ? nb.w : nb.z;
     const int others0 = r0e & 0x7fffffff, others1 = r1e & 0x7fffffff, others2 = r2e & 0x7fffffff;
     const bool oflip0 = r0e < 0, oflip1 = r1e < 0, oflip2 = r2e < 0;
     const bool cur_flip = (m0 ? tr.x : (m1 ? tr.y : (m2 ? tr.z : tr.w))) < 0;
-    // the three candidate faces: independent 64-byte records of this view, all in flight together
+    // the three candidate faces: independent 64-byte records, all in flight together
     // (a face id outside [0, F) -- malformed tet_faces -- never hits instead of reading out of bounds)
     const bool oval0 = (unsigned)others0 < (unsigned)p.F, oval1 = (unsigned)others1 < (unsigned)p.F, oval2 = (unsigned)others2 < (unsigned)p.F;
-    const int64_t vf = (int64_t)b * p.F;
-    const TetFaceRec r0 = load_facerec(p.facerec, vf + (oval0 ? others0 : 0));
-    const TetFaceRec r1 = load_facerec(p.facerec, vf + (oval1 ? others1 : 0));
-    const TetFaceRec r2 = load_facerec(p.facerec, vf + (oval2 ? others2 : 0));
+    const TetFaceRec r0 = load_facerec(p.facerec, oval0 ? others0 : 0);
+    const TetFaceRec r1 = load_facerec(p.facerec, oval1 ? others1 : 0);
+    const TetFaceRec r2 = load_facerec(p.facerec, oval2 ? others2 : 0);
     bool ok = true;
     const float dcur0 = dot(curr_n, rd);  // the current face's unit normal came with the previous step
     const float dcur = cur_flip ? -dcur0 : dcur0;
     if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
-    int nf = -1, ncnt = 0, nt = -1;
+    int nf = -1, ncnt = 0, nft0 = -1, nft1 = -1;
     float nrt = 0, niu = 0, niv = 0;
     V3 nn = {0, 0, 0};
     bool amb = false;
-    auto test = [&](const TetFaceRec& r, int of, bool flip, bool val, int behind) {
+    auto test = [&](const TetFaceRec& r, int of, bool flip, bool val) {
         V3 tuv;
-        const bool hit = hit_rec(rd, r, tuv) && val;
+        const bool hit = ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
+                                     {r.p2[0], r.p2[1], r.p2[2]}, tuv) && val;
         const float dn = oriented_dot(r, flip, rd);
         if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) {
-            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nt = behind; nn = {r.n[0], r.n[1], r.n[2]}; ncnt++;
+            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; nn = {r.n[0], r.n[1], r.n[2]}; ncnt++;
         }
+#ifndef DMR_TET_NO_AMB
         if (FWD && hit && dn < 0.0f) amb = true;
+#endif
     };
-    test(r0, others0, oflip0, oval0, nb0);
-    test(r1, others1, oflip1, oval1, nb1);
-    test(r2, others2, oflip2, oval2, nb2);
+    test(r0, others0, oflip0, oval0);
+    test(r1, others1, oflip1, oval1);
+    test(r2, others2, oflip2, oval2);
     if (ncnt != 1 || !ok) return false;
     if (FWD && back_amb) *back_amb = amb;
+    int nt = -1;
+    if (!(nft0 == curr_tet || nft0 == -1)) nt = nft0;
+    else if (!(nft1 == curr_tet || nft1 == -1)) nt = nft1;
     curr_face = nf; curr_tet = nt; curr_rt = nrt; curr_iu = niu; curr_iv = niv; curr_n = nn;
     return true;
 }
@@ -348,7 +314,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
     V3 curr_n = {0, 0, 0};
     if (first_face == -1 || first_tet == -1) done = true;
-    else face_tuv(p, b, rd, first_face, curr_rt, curr_iu, curr_iv, curr_n);
+    else face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv, curr_n);
 
     // the march sequence (dmr_kernels.hpp): this lane's 16-byte words, one per four steps, 64 words apart
     const uint32_t seq_cap = p.img.seq->cap_steps;
@@ -395,7 +361,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         last_face = curr_face;
         last_tet = curr_tet;
         if (curr_tet == -1) { active = true; done = true; }
-        if (!done && !march_step<true>(p, b, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n, &back_amb)) done = true;
+        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n, &back_amb)) done = true;
     }
     if (DMR_TET_SEQ_MODE != 0) {   // the wave's longest march (complete sequence? the next call's estimate)
         const uint32_t steps = wave_max_u32(n_contrib);
@@ -461,11 +427,12 @@ __device__ __forceinline__ F3 operator*(float b, F3 a) { return {b * a.x, b * a.
 __device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-// (t, u, v) of cuda_renderer/auxiliary.h:265-296 from a face's record, without the hit test (the march already decided)
-__device__ __forceinline__ void tuv(F3 d, F3 T, F3 E1, F3 E2, F3 Q, float tnum, float& t, float& u, float& v) {
-    const F3 P = cross(d, E2);
+// (t, u, v) of cuda_renderer/auxiliary.h:265-296 without the hit test (the march already decided)
+__device__ __forceinline__ void tuv(F3 o, F3 d, F3 p0, F3 p1, F3 p2, float& t, float& u, float& v) {
+    const F3 T = o - p0, E1 = p1 - p0, E2 = p2 - p0;
+    const F3 P = cross(d, E2), Q = cross(T, E1);
     const float inv = rcp(dot(P, E1));
-    t = tnum * inv; u = dot(P, T) * inv; v = dot(Q, d) * inv;
+    t = dot(Q, E2) * inv; u = dot(P, T) * inv; v = dot(Q, d) * inv;
 }
 // ndc depth of a world point: rows z and w of proj * (mv * (pt, 1)) (auxiliary.h:71-90), z / clamp_w(w)
 __device__ __forceinline__ float ndc_depth(F3 pt, const float* __restrict__ mv, const float* __restrict__ pr) {
@@ -535,13 +502,13 @@ struct TetBwdPixel {
     }
     // the same with tfast's arithmetic, from the face's records (k_tet_backward_seq)
     __device__ __forceinline__ void face_grad_fast(V3 ro, V3 rd, const float* __restrict__ mv, const float* __restrict__ pr,
-                                                   float4 f0, float4 f1, float4 f2, float tnum, float4 cq0, float4 cq1, float4 cq2,
-                                                   float4 cq3, float intense, float (&g)[10], int& v0, int& v1, int& v2) {
+                                                   float4 f0, float4 f1, float4 f2, float4 cq0, float4 cq1, float4 cq2, float4 cq3,
+                                                   float intense, float (&g)[10], int& v0, int& v1, int& v2) {
 #pragma clang fp contract(fast)
         using namespace tfast;
         const F3 o = {ro.x, ro.y, ro.z}, d = {rd.x, rd.y, rd.z};
-        float rt, iu, iv;  // (TetFaceRec: T, E1, E2, Q, tnum)
-        tuv(d, {f0.x, f0.y, f0.z}, {f0.w, f1.x, f1.y}, {f1.z, f1.w, f2.x}, {f2.y, f2.z, f2.w}, tnum, rt, iu, iv);
+        float rt, iu, iv;
+        tuv(o, d, {f0.x, f0.y, f0.z}, {f0.w, f1.x, f1.y}, {f1.z, f1.w, f2.x}, rt, iu, iv);
         const F3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
         v0 = __float_as_int(cq2.y); v1 = __float_as_int(cq2.z); v2 = __float_as_int(cq2.w);
         const float i0 = 1.0f - iu - iv, i1 = iu, i2 = iv;
@@ -723,7 +690,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
     V3 curr_n = {0, 0, 0};
     if (!done) {
         curr_tet = p.img.last_tet[(int64_t)b * p.H * p.W + (int64_t)p.W * py + px];
-        face_tuv(p, b, rd, last_face, curr_rt, curr_iu, curr_iv, curr_n);
+        face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv, curr_n);
         // step back across the last face (backward.cu:223-232)
         for (int i = 0; i < 2; i++) {
             const int t = p.face_tets[2 * curr_face + i];
@@ -742,7 +709,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
             if (curr_face == first_face) done = true;
             if (!done) {
                 if (curr_tet == -1) done = true;
-                else if (!march_step<false>(p, b, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
+                else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
             }
         }
         tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
@@ -791,13 +758,13 @@ k_tet_backward_seq(TetParams p, const float* __restrict__ dL_dcolor, const float
         // The load stream runs ahead of the arithmetic: the sequence says which records step s - 1 needs while step s is
         // being computed (the reference's -- and the fallback's -- reverse march cannot know: there a step is a chain of
         // dependent gathers, tet record -> three face records -> tests -> colour record).
-        struct Recs { float4 f0, f1, f2, c0, c1, c2, c3; float tnum, intense; };
+        struct Recs { float4 f0, f1, f2, c0, c1, c2, c3; float intense; };
         auto load_recs = [&](uint32_t e, Recs& r) {
             if (e == 0xffffffffu) return;  // this lane has no such step (not joined yet, or below step 0)
             const int face = (int)(e & 0x7fffffffu);
-            const float4* fq = reinterpret_cast<const float4*>(p.facerec + ((int64_t)b * p.F + face));
+            const float4* fq = reinterpret_cast<const float4*>(p.facerec + face);
             const float4* cq = reinterpret_cast<const float4*>(p.colrec + face);
-            r.f0 = fq[0]; r.f1 = fq[1]; r.f2 = fq[2]; r.tnum = reinterpret_cast<const float*>(fq)[12];
+            r.f0 = fq[0]; r.f1 = fq[1]; r.f2 = fq[2];
             r.c0 = cq[0]; r.c1 = cq[1]; r.c2 = cq[2]; r.c3 = cq[3];
             r.intense = p.faces_intense[(int64_t)b * p.F + face];
         };
@@ -832,7 +799,7 @@ k_tet_backward_seq(TetParams p, const float* __restrict__ dL_dcolor, const float
             float g[10];
             int v0 = 0, v1 = 0, v2 = 0;
             if (act) {  // (t, u, v) of the ray on this face, then the face's gradient
-                st.face_grad_fast(ro, rd, mv, pr, cur.f0, cur.f1, cur.f2, cur.tnum, cur.c0, cur.c1, cur.c2, cur.c3, cur.intense, g, v0, v1, v2);
+                st.face_grad_fast(ro, rd, mv, pr, cur.f0, cur.f1, cur.f2, cur.c0, cur.c1, cur.c2, cur.c3, cur.intense, g, v0, v1, v2);
                 if (face == first_face || (e_cur & 0x80000000u)) done = true;
             }
             tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
@@ -861,24 +828,23 @@ static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImag
     p.seed = img.seed;
     p.facerec = reinterpret_cast<const TetFaceRec*>(img.facerec);
     p.colrec = reinterpret_cast<const TetColRec*>(img.colrec);
-    p.tetrec = reinterpret_cast<const TetRec*>(img.tetrec);
+    p.tetrec = reinterpret_cast<const int4*>(img.tetrec);
     p.img = img;
     return p;
 }
 
-size_t tet_facerec_bytes() { return sizeof(TetFaceRec); }   // per (view, face)
-size_t tet_tetrec_bytes() { return sizeof(TetRec); }
+size_t tet_facerec_bytes() { return sizeof(TetFaceRec); }
 size_t tet_colrec_bytes() { return sizeof(TetColRec); }
 
 void launch_tet_prep(const dmr_scene& s, TetImageState img, uint32_t seq_steps, unsigned long long seq_offset, hipStream_t st) {
     k_tet_prep_faces<<<dim3((unsigned)std::max(1, (s.F + 255) / 256)), dim3(256), 0, st>>>(
-        s.B, s.F, s.verts, s.faces, s.verts_color, s.faces_opacity, s.inv_mv_mats,
+        s.F, s.verts, s.faces, s.verts_color, s.faces_opacity, s.face_tets,
         reinterpret_cast<TetFaceRec*>(img.facerec), reinterpret_cast<TetColRec*>(img.colrec), s.ray_random_seed, img.seed,
         img.seq, seq_steps, seq_offset);
     if (s.T > 0)
         k_tet_prep_tets<<<dim3((unsigned)((s.T + 255) / 256)), dim3(256), 0, st>>>(
-            s.T, s.F, s.verts, s.faces, s.tets, s.tet_faces, s.face_tets, reinterpret_cast<const TetFaceRec*>(img.facerec),
-            reinterpret_cast<TetRec*>(img.tetrec));
+            s.T, s.F, s.verts, s.tets, s.tet_faces, reinterpret_cast<const TetFaceRec*>(img.facerec),
+            reinterpret_cast<int4*>(img.tetrec));
 }
 
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
