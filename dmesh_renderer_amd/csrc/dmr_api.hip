@@ -72,7 +72,7 @@ size_t carve_face(void* b, size_t BF, size_t F, size_t T, bool tet, FaceState& s
     if (tet) {  // packed march records (view independent)
         s.facerec = c.take<char>(F * dmr::tet_facerec_bytes());
         s.colrec = c.take<char>(F * dmr::tet_colrec_bytes());
-        s.tetrec = c.take<int4>(T);
+        s.tetrec = c.take<char>(T * dmr::tet_tetrec_bytes());
     }
     return c.off;
 }
@@ -144,6 +144,7 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     d.ntiles = s->B * d.gx * d.gy;
     d.BP = (size_t)s->B * s->P; d.BF = (size_t)s->B * s->F; d.npix = (size_t)s->B * s->W * s->H;
     if (tet && s->F > 0 && s->P > 0 && (!s->tets || !s->face_tets || !s->tet_faces)) return fail("tet topology missing");
+    if (tet && s->F >= (1 << 29)) return fail("too many faces for the tet renderer (face ids must fit 29 bits)");
     return 0;
 }
 

@@ -150,8 +150,9 @@ struct TetImageState {
     TetSeq* seq;                                // the march sequence's descriptor (image buffer)
     char* binning;                              // start of the binning buffer (the sequence region lies at seq->offset)
 };
-size_t tet_facerec_bytes();
-size_t tet_colrec_bytes();
+size_t tet_facerec_bytes();   // per face
+size_t tet_colrec_bytes();    // per face
+size_t tet_tetrec_bytes();    // per tet
 // builds the packed march records from the scene (every forward call); also resets the march sequence's descriptor:
 // room for seq_steps steps per pixel at byte seq_offset of the binning buffer
 void launch_tet_prep(const dmr_scene& s, TetImageState img, uint32_t seq_steps, unsigned long long seq_offset, hipStream_t st);

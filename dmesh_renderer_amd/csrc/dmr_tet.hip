@@ -29,6 +29,14 @@ static_assert(sizeof(TetFaceRec) == 64, "TetFaceRec");
 struct alignas(16) TetColRec { float c0[3], c1[3], c2[3]; int v0, v1, v2; float opacity, log1m; int pad[2]; };
 static_assert(sizeof(TetColRec) == 64, "TetColRec");
 
+// Per tet: everything a march step needs of it, in ONE 224-byte record -- its four faces (id | slot of the face in the tet
+// behind it << 29 | orientation flip << 31), the tets behind them (-1: none) and, per face, the three vertices and the unit
+// normal before orientation.  A step used to be tet record -> three face records: two dependent levels of gathers; the march
+// now carries the slot its current face has in its current tet, so the step's eleven loads go out together, one level.
+struct alignas(16) TetBlock { int face[4]; int nbr[4]; float geo[4][12]; };
+static_assert(sizeof(TetBlock) == 224, "TetBlock");
+constexpr int TET_FACE_MASK = 0x1fffffff;  // (check_scene: F < 2^29)
+
 struct TetParams {
     int B, P, F, W, H, gx, gy, r0;
 #ifdef DMR_ABLATION
@@ -39,7 +47,7 @@ struct TetParams {
     const float* faces_intense; const float* bg;
     const int* tets; const int* face_tets; const int* tet_faces;
     const int* seed;  // ray_random_seed of the forward, kept in the image buffer for the backward
-    const TetFaceRec* facerec; const TetColRec* colrec; const int4* tetrec;
+    const TetFaceRec* facerec; const TetColRec* colrec; const TetBlock* tetrec;
     TetImageState img;
 };
 
@@ -51,9 +59,11 @@ struct TetParams {
 // on the ray is hoisted here, with the reference's arithmetic, so the decisions stay bit-identical:
 //   TetFaceRec : the three vertices, the UNIT normal before orientation, face_tets, opacity -- one 64-byte line
 //   TetColRec  : the three vertex colours and ids, the opacity and logf(1 - opacity) -- one 64-byte line
-//   tetrec     : the four faces of a tet, bit 31 set where tet_face_outward_normal flips the unit normal
-//                (dot(n, centre - p0) > 0, cuda_renderer/auxiliary.h:386-392); dot(-n, d) == -dot(n, d) exactly.
-// A step is then tetrec -> 3 x TetFaceRec: two dependent levels of 16-byte loads.
+//   TetBlock   : per tet (above); bit 31 of a face entry is set where tet_face_outward_normal flips the unit normal
+//                (dot(n, centre - p0) > 0, cuda_renderer/auxiliary.h:386-392); dot(-n, d) == -dot(n, d) exactly; the tet
+//                behind a face follows the reference's rule (the first entry of face_tets[face] that is neither this tet
+//                nor -1, forward.cu:761-767).
+// A step is then ONE level of 16-byte loads (TetBlock), then the chosen face's TetColRec for the shading.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_tet_prep_faces(int F, const float* __restrict__ verts, const int* __restrict__ faces,
@@ -91,22 +101,51 @@ k_tet_prep_faces(int F, const float* __restrict__ verts, const int* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-k_tet_prep_tets(int T, int F, const float* __restrict__ verts, const int* __restrict__ tets,
-                const int* __restrict__ tet_faces, const TetFaceRec* __restrict__ facerec, int4* __restrict__ tetrec) {
+k_tet_prep_tets(int T, int F, const float* __restrict__ verts, const int* __restrict__ faces, const int* __restrict__ tets,
+                const int* __restrict__ tet_faces, const int* __restrict__ face_tets, TetBlock* __restrict__ tetrec) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const V3 center = tet_center(verts, tets, t);
-    int f[4];
+    TetBlock r;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        f[i] = tet_faces[4 * t + i];
-        if (f[i] >= 0 && f[i] < F) {
-            const TetFaceRec& r = facerec[f[i]];
-            const V3 n = {r.n[0], r.n[1], r.n[2]}, p0 = {r.p0[0], r.p0[1], r.p0[2]};
-            if (dot(n, center - p0) > 0.0f) f[i] |= (int)0x80000000;
+        int f = tet_faces[4 * t + i];
+        int nbr = -1;
+        V3 p0 = {0, 0, 0}, p1 = p0, p2 = p0, n = p0;
+        if (f >= 0 && f < F) {
+            p0 = load_v3(verts, faces[3 * f]); p1 = load_v3(verts, faces[3 * f + 1]); p2 = load_v3(verts, faces[3 * f + 2]);
+            n = cross(p1 - p0, p2 - p0);  // as k_tet_prep_faces (cuda_renderer/auxiliary.h:375-384): the same bits
+            float n_norm = sqrtf(dot(n, n));
+            n_norm = fmaxf(n_norm, 0.0001f);
+            n = n / n_norm;
+            const int ft0 = face_tets[2 * f], ft1 = face_tets[2 * f + 1];
+            if (!(ft0 == t || ft0 == -1)) nbr = ft0;
+            else if (!(ft1 == t || ft1 == -1)) nbr = ft1;
+            int nslot = 0;  // the slot of this face in the tet behind it (first match, like every look-up of the march)
+            if (nbr >= 0 && nbr < T) {
+                for (int q = 3; q >= 0; q--) if (tet_faces[4 * nbr + q] == f) nslot = q;
+            }
+            const bool flip = dot(n, center - p0) > 0.0f;
+            f = f | (nslot << 29) | (flip ? (int)0x80000000 : 0);
         }
+        r.face[i] = f; r.nbr[i] = nbr;
+        r.geo[i][0] = p0.x; r.geo[i][1] = p0.y; r.geo[i][2] = p0.z;
+        r.geo[i][3] = p1.x; r.geo[i][4] = p1.y; r.geo[i][5] = p1.z;
+        r.geo[i][6] = p2.x; r.geo[i][7] = p2.y; r.geo[i][8] = p2.z;
+        r.geo[i][9] = n.x; r.geo[i][10] = n.y; r.geo[i][11] = n.z;
     }
-    tetrec[t] = make_int4(f[0], f[1], f[2], f[3]);
+    tetrec[t] = r;
+}
+
+// the slot `face` has in `tet` (first match; 0 if there is none: the march's own check stops it then)
+__device__ __forceinline__ int tet_slot_of(const TetBlock* __restrict__ tetrec, int tet, int face) {
+    const int4 hd = *reinterpret_cast<const int4*>(tetrec[tet].face);
+    int slot = 0;
+    if ((hd.w & TET_FACE_MASK) == face) slot = 3;
+    if ((hd.z & TET_FACE_MASK) == face) slot = 2;
+    if ((hd.y & TET_FACE_MASK) == face) slot = 1;
+    if ((hd.x & TET_FACE_MASK) == face) slot = 0;
+    return slot;
 }
 
 __device__ __forceinline__ TetFaceRec load_facerec(const TetFaceRec* __restrict__ a, int f) {
@@ -197,11 +236,11 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
         for (int i = 0; i < 2; i++) {
             const int tet_id = i == 0 ? fr.ft0 : fr.ft1;
             if (tet_id < 0) continue;
-            const int4 tr = p.tetrec[tet_id];
+            const int4 tr = *reinterpret_cast<const int4*>(p.tetrec[tet_id].face);
             const int e[4] = {tr.x, tr.y, tr.z, tr.w};
             bool flip = false;
 #pragma unroll
-            for (int q = 0; q < 4; q++) if ((e[q] & 0x7fffffff) == ff) flip = e[q] < 0;
+            for (int q = 0; q < 4; q++) if ((e[q] & TET_FACE_MASK) == ff) flip = e[q] < 0;
             if (oriented_dot(fr, flip, rd) < 0.0f) ft = tet_id;
         }
     }
@@ -227,54 +266,53 @@ __device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int f
 // always qualifies there (it was accepted as a hit with this ray, and its normal is checked below), so this flag is all the
 // backward needs to know of this tet.
 template <bool FWD>
-__device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet,
+__device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet, int& curr_slot,
                                            float& curr_rt, float& curr_iu, float& curr_iv, V3& curr_n, bool* back_amb = nullptr) {
-    const int4 tr = p.tetrec[curr_tet];
-    // The three faces of the tet other than the current one, in the record's order, with their orientation bits --
-    // by selects, not by indexing small arrays (which the compiler put in scratch memory: 12 scratch accesses per step).
-    const int t0 = tr.x & 0x7fffffff, t1 = tr.y & 0x7fffffff, t2 = tr.z & 0x7fffffff, t3 = tr.w & 0x7fffffff;
+    // The tet's record: header and the three faces other than the current one (whose slot the march carries), all requested
+    // at once.  `others` keep the record's order, as the reference's loop over tet_faces does.
+    const char* base = reinterpret_cast<const char*>(p.tetrec + curr_tet);
+    const bool s1 = curr_slot == 0, s2 = curr_slot <= 1, s3 = curr_slot <= 2;  // entry i of `others` is slot i + (shift i)
+    const float4* g0 = reinterpret_cast<const float4*>(base + 32 + 48 * (s1 ? 1 : 0));
+    const float4* g1 = reinterpret_cast<const float4*>(base + 32 + 48 * (s2 ? 2 : 1));
+    const float4* g2 = reinterpret_cast<const float4*>(base + 32 + 48 * (s3 ? 3 : 2));
+    const int4 tr = reinterpret_cast<const int4*>(base)[0], nb = reinterpret_cast<const int4*>(base)[1];
+    const float4 a0 = g0[0], a1 = g0[1], a2 = g0[2];
+    const float4 b0 = g1[0], b1 = g1[1], b2 = g1[2];
+    const float4 c0 = g2[0], c1 = g2[1], c2 = g2[2];
+    const int t0 = tr.x & TET_FACE_MASK, t1 = tr.y & TET_FACE_MASK, t2 = tr.z & TET_FACE_MASK, t3 = tr.w & TET_FACE_MASK;
     const bool m0 = t0 == curr_face, m1 = t1 == curr_face, m2 = t2 == curr_face, m3 = t3 == curr_face;
-    if ((int)m0 + (int)m1 + (int)m2 + (int)m3 != 1) return false;  // the reference's `cnt != 3`
-    const bool s1 = m0, s2 = m0 || m1, s3 = s2 || m2;  // entry i of `others` is record entry i + (shift i)
+    if ((int)m0 + (int)m1 + (int)m2 + (int)m3 != 1) return false;  // the reference's `cnt != 3` (then the slot is the match's)
     const int r0e = s1 ? tr.y : tr.x, r1e = s2 ? tr.z : tr.y, r2e = s3 ? tr.w : tr.z;
-    const int others0 = r0e & 0x7fffffff, others1 = r1e & 0x7fffffff, others2 = r2e & 0x7fffffff;
-    const bool oflip0 = r0e < 0, oflip1 = r1e < 0, oflip2 = r2e < 0;
+    const int nb0 = s1 ? nb.y : nb.x, nb1 = s2 ? nb.z : nb.y, nb2 = s3 ? nb.w : nb.z;
     const bool cur_flip = (m0 ? tr.x : (m1 ? tr.y : (m2 ? tr.z : tr.w))) < 0;
-    // the three candidate faces: independent 64-byte records, all in flight together
-    // (a face id outside [0, F) -- malformed tet_faces -- never hits instead of reading out of bounds)
-    const bool oval0 = (unsigned)others0 < (unsigned)p.F, oval1 = (unsigned)others1 < (unsigned)p.F, oval2 = (unsigned)others2 < (unsigned)p.F;
-    const TetFaceRec r0 = load_facerec(p.facerec, oval0 ? others0 : 0);
-    const TetFaceRec r1 = load_facerec(p.facerec, oval1 ? others1 : 0);
-    const TetFaceRec r2 = load_facerec(p.facerec, oval2 ? others2 : 0);
     bool ok = true;
     const float dcur0 = dot(curr_n, rd);  // the current face's unit normal came with the previous step
     const float dcur = cur_flip ? -dcur0 : dcur0;
     if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
-    int nf = -1, ncnt = 0, nft0 = -1, nft1 = -1;
+    int nf = -1, ncnt = 0, nt = -1, ns = 0;
     float nrt = 0, niu = 0, niv = 0;
     V3 nn = {0, 0, 0};
     bool amb = false;
-    auto test = [&](const TetFaceRec& r, int of, bool flip, bool val) {
+    // q0..q2: p0, p1, p2, unit normal of the candidate; e: its header entry; behind: the tet on its other side
+    // (a face id outside [0, F) -- malformed tet_faces -- never hits)
+    auto test = [&](float4 q0, float4 q1, float4 q2, int e, int behind) {
+        const int of = e & TET_FACE_MASK;
         V3 tuv;
-        const bool hit = ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
-                                     {r.p2[0], r.p2[1], r.p2[2]}, tuv) && val;
-        const float dn = oriented_dot(r, flip, rd);
+        const bool hit = ray_tri_hit(ro, rd, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}, tuv) && (unsigned)of < (unsigned)p.F;
+        const V3 n = {q2.y, q2.z, q2.w};
+        const float dn0 = dot(n, rd);
+        const float dn = e < 0 ? -dn0 : dn0;
         if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) {
-            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nft0 = r.ft0; nft1 = r.ft1; nn = {r.n[0], r.n[1], r.n[2]}; ncnt++;
+            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nt = behind; ns = (e >> 29) & 3; nn = n; ncnt++;
         }
-#ifndef DMR_TET_NO_AMB
         if (FWD && hit && dn < 0.0f) amb = true;
-#endif
     };
-    test(r0, others0, oflip0, oval0);
-    test(r1, others1, oflip1, oval1);
-    test(r2, others2, oflip2, oval2);
+    test(a0, a1, a2, r0e, nb0);
+    test(b0, b1, b2, r1e, nb1);
+    test(c0, c1, c2, r2e, nb2);
     if (ncnt != 1 || !ok) return false;
     if (FWD && back_amb) *back_amb = amb;
-    int nt = -1;
-    if (!(nft0 == curr_tet || nft0 == -1)) nt = nft0;
-    else if (!(nft1 == curr_tet || nft1 == -1)) nt = nft1;
-    curr_face = nf; curr_tet = nt; curr_rt = nrt; curr_iu = niu; curr_iv = niv; curr_n = nn;
+    curr_face = nf; curr_tet = nt; curr_slot = ns; curr_rt = nrt; curr_iu = niu; curr_iv = niv; curr_n = nn;
     return true;
 }
 
@@ -313,8 +351,12 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     int curr_face = first_face, curr_tet = first_tet;
     float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
     V3 curr_n = {0, 0, 0};
+    int curr_slot = 0;  // the slot of curr_face in curr_tet's record
     if (first_face == -1 || first_tet == -1) done = true;
-    else face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv, curr_n);
+    else {
+        face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv, curr_n);
+        curr_slot = tet_slot_of(p.tetrec, first_tet, first_face);
+    }
 
     // the march sequence (dmr_kernels.hpp): this lane's 16-byte words, one per four steps, 64 words apart
     const uint32_t seq_cap = p.img.seq->cap_steps;
@@ -361,7 +403,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         last_face = curr_face;
         last_tet = curr_tet;
         if (curr_tet == -1) { active = true; done = true; }
-        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n, &back_amb)) done = true;
+        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_n, &back_amb)) done = true;
     }
     if (DMR_TET_SEQ_MODE != 0) {   // the wave's longest march (complete sequence? the next call's estimate)
         const uint32_t steps = wave_max_u32(n_contrib);
@@ -685,7 +727,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
     bool done = !tet_bwd_begin(p, b, px, py, dL_dcolor, dL_ddepth, st, ro, rd, first_face, last_face);
     const float* mv = p.mv + 16 * b;
     const float* pr = p.proj + 16 * b;
-    int curr_face = last_face, curr_tet = -1;
+    int curr_face = last_face, curr_tet = -1, curr_slot = 0;
     float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
     V3 curr_n = {0, 0, 0};
     if (!done) {
@@ -698,6 +740,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
             curr_tet = t;
             break;
         }
+        if (curr_tet >= 0) curr_slot = tet_slot_of(p.tetrec, curr_tet, curr_face);
     }
     while (!__all(done)) {  // the wave's lanes stay together: tet_accumulate merges lanes that hold the same face
         const bool act = !done;
@@ -709,7 +752,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
             if (curr_face == first_face) done = true;
             if (!done) {
                 if (curr_tet == -1) done = true;
-                else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
+                else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
             }
         }
         tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
@@ -828,13 +871,14 @@ static TetParams make_params(const dmr_scene& s, int gx, int gy, int r0, TetImag
     p.seed = img.seed;
     p.facerec = reinterpret_cast<const TetFaceRec*>(img.facerec);
     p.colrec = reinterpret_cast<const TetColRec*>(img.colrec);
-    p.tetrec = reinterpret_cast<const int4*>(img.tetrec);
+    p.tetrec = reinterpret_cast<const TetBlock*>(img.tetrec);
     p.img = img;
     return p;
 }
 
 size_t tet_facerec_bytes() { return sizeof(TetFaceRec); }
 size_t tet_colrec_bytes() { return sizeof(TetColRec); }
+size_t tet_tetrec_bytes() { return sizeof(TetBlock); }
 
 void launch_tet_prep(const dmr_scene& s, TetImageState img, uint32_t seq_steps, unsigned long long seq_offset, hipStream_t st) {
     k_tet_prep_faces<<<dim3((unsigned)std::max(1, (s.F + 255) / 256)), dim3(256), 0, st>>>(
@@ -843,8 +887,7 @@ void launch_tet_prep(const dmr_scene& s, TetImageState img, uint32_t seq_steps, 
         img.seq, seq_steps, seq_offset);
     if (s.T > 0)
         k_tet_prep_tets<<<dim3((unsigned)((s.T + 255) / 256)), dim3(256), 0, st>>>(
-            s.T, s.F, s.verts, s.tets, s.tet_faces, reinterpret_cast<const TetFaceRec*>(img.facerec),
-            reinterpret_cast<int4*>(img.tetrec));
+            s.T, s.F, s.verts, s.faces, s.tets, s.tet_faces, s.face_tets, reinterpret_cast<TetBlock*>(img.tetrec));
 }
 
 void launch_tet_first_intersect(const dmr_scene& s, int gx, int gy, int r0, int r1, const float* key_depth,
