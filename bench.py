@@ -303,13 +303,13 @@ def main():
         R, npix_band = R_full, B * W * H
     if tet:
         # The march kernels' algorithmic bytes are this design's compulsory HBM traffic: the packed
-        # march records once per launch (128 B per face + 16 B per tet: the mesh stays in L2, its per-step gathers are
+        # march records once per launch (128 B per face + 224 B per tet: the mesh stays in L2, its per-step gathers are
         # not HBM traffic), the march sequence (4 B per marched pair S, written by the forward, read by the backward)
         # and the per-pixel state / images.  SURVEY 8(d)'s 508 / 548 B per step price the REFERENCE's gathers; against
         # the HBM peak they gave a "fraction" of 2.3 (round 2), which is not a roofline.
         S = int(_C.export("n_contrib", args, True, 0, o[-4:], H, W, th.int32).sum().item())
         T = int(d["tets"].shape[0])
-        mesh = 128.0 * F + 16.0 * T
+        mesh = 128.0 * F + 224.0 * T
         alg = {_C.STAGE_TET_FIRST: 52.0 * R + 8.0 * npix_band,
                _C.STAGE_TET_FORWARD: mesh + 4.0 * S + (8 + 21 + 20) * npix_band,   # first face/tet in; state 21 B, colour/depth/active 20 B out
                _C.STAGE_TET_BACKWARD: mesh + 4.0 * S + (21 + 8 + 16) * npix_band + 2 * 4.0 * (3 * P + F)}  # state, first face/tet, dL_dpix in; gradients RMW

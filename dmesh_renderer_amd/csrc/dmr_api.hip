@@ -159,7 +159,10 @@ SizeRead* size_read() {
     SizeRead& sr = per_device[dev];
     if (!sr.slot) {
         if (hipHostMalloc(&sr.slot, 64, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { sr.slot = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
+#ifndef DMR_SIZE_EVENT_FLAGS
+#define DMR_SIZE_EVENT_FLAGS (hipEventDisableTiming | hipEventReleaseToSystem)
+#endif
+        if (hipEventCreateWithFlags(&sr.ev, DMR_SIZE_EVENT_FLAGS) != hipSuccess) {
             (void)hipHostFree(sr.slot); sr.slot = nullptr; return nullptr;
         }
     }

@@ -441,17 +441,23 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
 // precision: ds_add_f32 retires one lane per ~3 cycles per CU, ds_add_f64 ten times that
 // (scripts/micro/lds_atomics.hip: 194 vs 20 cycles per conflict-free wave instruction), and this kernel was
 // bound by exactly those adds (10 per marched face and pixel).
-constexpr int TET_TBL = 512;     // slots (power of two)
+#ifndef DMR_TET_TBL
+#define DMR_TET_TBL 512
+#endif
+#ifndef DMR_TET_BWD_WAVES
+#define DMR_TET_BWD_WAVES 1
+#endif
+constexpr int TET_TBL = DMR_TET_TBL;     // slots (a multiple of 16)
 constexpr int TET_PROBES = 8;
 
 struct TetAccum {
     int* key; double (*val)[TET_TBL];
     __device__ __forceinline__ int find(int face) const {
-        uint32_t slot = ((uint32_t)face * 2654435761u) >> 23;  // top 9 bits
+        uint32_t slot = __umulhi((uint32_t)face * 2654435761u, (uint32_t)TET_TBL);
         for (int i = 0; i < TET_PROBES; i++) {
             const int prev = atomicCAS(&key[slot], -1, face);
             if (prev == -1 || prev == face) return (int)slot;
-            slot = (slot + 1) & (TET_TBL - 1);
+            slot = slot + 1u == (uint32_t)TET_TBL ? 0u : slot + 1u;
         }
         return -1;
     }
@@ -767,7 +773,7 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
 // picked, here with contracted arithmetic (tfast: nothing is decided by it) -- instead of the tet record, three candidate
 // records, three tests and the orientation logic.  Stops where the reference stops: behind first_face, or behind an entry
 // whose bit 31 says the reverse march would find two candidates there.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DMR_TET_BWD_WAVES)
 k_tet_backward_seq(TetParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    float* __restrict__ dL_dvcolor, float* __restrict__ dL_dfopacity, uint32_t* __restrict__ host_seq_steps) {
     const uint32_t seq_cap = p.img.seq->cap_steps, longest = p.img.seq->max_steps;

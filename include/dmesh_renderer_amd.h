@@ -42,7 +42,7 @@ extern "C" {
 enum { DMR_BUF_POINT = 0, DMR_BUF_FACE = 1, DMR_BUF_BINNING = 2, DMR_BUF_IMAGE = 3, DMR_BUF_WORK = 4 };
 
 /* Footprints (bytes; B views, P verts, F faces, T tets, Nt = B * ceil(W/16) * ceil(H/16) tiles, R list entries; every
- * sub-array rounded up to 256): point 16 BP; face 16 BF (tet: 20 BF + 128 F + 16 T); image ~76 B + 40 Nt + 12 BWH (tet: 29 BWH);
+ * sub-array rounded up to 256): point 16 BP; face 16 BF (tet: 20 BF + 128 F + 224 T); image ~76 B + 40 Nt + 12 BWH (tet: 29 BWH);
  * binning 12 R', R' = R or, with a size estimate, 1.25 R_prev + 4096 -- plus, tri only, the coverage masks the forward
  * leaves for the backward: 4096 (R'/128 + Nt + 1), i.e. 32 B per list entry AND 4 KB PER TILE, busy or not (the reference's
  * binning buffer scales with R only: a 1 M-tile frame costs 4 GiB here) -- plus, tet only, the forward's march sequence for
