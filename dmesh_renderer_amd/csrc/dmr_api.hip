@@ -159,10 +159,7 @@ SizeRead* size_read() {
     SizeRead& sr = per_device[dev];
     if (!sr.slot) {
         if (hipHostMalloc(&sr.slot, 64, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { sr.slot = nullptr; return nullptr; }
-#ifndef DMR_SIZE_EVENT_FLAGS
-#define DMR_SIZE_EVENT_FLAGS (hipEventDisableTiming | hipEventReleaseToSystem)
-#endif
-        if (hipEventCreateWithFlags(&sr.ev, DMR_SIZE_EVENT_FLAGS) != hipSuccess) {
+        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
             (void)hipHostFree(sr.slot); sr.slot = nullptr; return nullptr;
         }
     }
