@@ -8,6 +8,7 @@
 // binning buffer.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -148,10 +149,15 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     return 0;
 }
 
-// pinned (coherent, device-visible) landing pad the scan kernels write the sizes to (forward: the int at byte 0,
-// backward: the 64-bit count at byte 8), and the event the host waits on; one per host thread and device (an event
-// belongs to the device it was created on)
-struct SizeRead { void* slot = nullptr; hipEvent_t ev = nullptr; };
+// Pinned (coherent, device-visible) landing pad the kernels write the sizes to -- forward: the 8-byte word at byte 0,
+// backward: the one at byte 8, each host_size_word(sequence number, size) (dmr_kernels.hpp) -- one per host thread and
+// device.  The host POLLS the word until it carries the call's sequence number: an event recorded between two kernels costs the
+// device 2-7 us (profiles/r03/dead_ends.md), a default call had two of them per step.
+struct SizeRead {
+    void* slot = nullptr; uint32_t seq = 0;
+    volatile unsigned long long* word(int which) const { return reinterpret_cast<volatile unsigned long long*>(slot) + which; }
+    uint32_t next_seq() { seq = (seq + 1u) & 0xffffffu; if (seq == 0u) seq = 1u; return seq; }
+};
 SizeRead* size_read() {
     thread_local std::map<int, SizeRead> per_device;
     int dev = 0;
@@ -159,11 +165,27 @@ SizeRead* size_read() {
     SizeRead& sr = per_device[dev];
     if (!sr.slot) {
         if (hipHostMalloc(&sr.slot, 64, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { sr.slot = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
-            (void)hipHostFree(sr.slot); sr.slot = nullptr; return nullptr;
-        }
+        memset(sr.slot, 0, 64);
     }
     return &sr;
+}
+// Waits until *w carries `seq`; returns the size in it.  Spins on the pinned word; if it does not arrive within ~50 ms the
+// stream is synchronised instead (a kernel error then surfaces as a HIP error, and a completed stream has written the word).
+int wait_size(volatile unsigned long long* w, uint32_t seq, hipStream_t st, unsigned long long* size) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const unsigned long long v = *w;
+        if ((uint32_t)(v >> 40) == (seq & 0xffffffu)) { std::atomic_thread_fence(std::memory_order_acquire); *size = v & ((1ull << 40) - 1ull); return 0; }
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    DMR_HIP(hipStreamSynchronize(st));
+    const unsigned long long v = *w;
+    if ((uint32_t)(v >> 40) != (seq & 0xffffffu)) return fail("the size word was not written (internal error)");
+    *size = v & ((1ull << 40) - 1ull);
+    return 0;
 }
 
 // Sticky per-device overflow word of the asynchronous / captured calls (pinned host memory the scan kernels store 1
@@ -192,8 +214,8 @@ bool stream_is_capturing(hipStream_t st) {
 // only known on the device.  The reference stalls the pipeline on a device->host read before it can continue
 // (rasterizer_impl.cu:287-299).  Here the previous call with the same view configuration provides a capacity guess
 // (its sizes per face / per list entry, +25 %): the buffer is allocated and ALL remaining kernels are enqueued
-// before the host waits -- and it waits on an event recorded right behind the kernel that writes the size to
-// pinned host memory, not on the stream, so the GPU keeps running.  Kernels clamp their writes to the capacity; if
+// before the host waits -- and it waits for the word the size-writing kernel stores into pinned host memory (polled: no
+// event packet, no stream synchronisation), so the GPU keeps running.  Kernels clamp their writes to the capacity; if
 // the exact size turns out larger the affected stages are simply enqueued again with an exact buffer (first call,
 // or a scene that grew by more than 25 %).
 // The guess is keyed by the view configuration only and kept as RATIOS (list entries and hit records per (view, face)
@@ -236,12 +258,12 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
 
     // host_R: pinned slot the scan also stores R into (null: not needed).  Not on a redo pass: R is known by then, and
     // a late store could land in the slot after this call has returned and a later call (another stream) reuses it.
-    auto front = [&](int* host_R, uint64_t capacity, uint32_t* ovf) -> int {
+    auto front = [&](unsigned long long* host_R, uint32_t host_seq, uint64_t capacity, uint32_t* ovf) -> int {
         // (tile_count | tile_hits | tile_bound are contiguous: zeroed by k_project_verts, a slice per block)
         dmr::launch_project_verts(*s, ps.vproj, is.mats, is.tile_count, (size_t)(is.scan_tmp + dmr::SCAN_TMP_BUCKETS - is.tile_count), st);
         dmr::launch_setup_faces(*s, tet, ps.vproj, d.gx, d.gy, d.r0, d.r1, fs.rect, fs.key_depth, fs.max_depth,
                                 fs.tiles_touched, is.tile_count, st);
-        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, is.tile_order,
+        dmr::launch_scan_tiles(d.ntiles, is.tile_count, is.tile_offset, is.tile_cursor, is.num_rendered, host_R, host_seq, is.tile_order,
                                is.scan_tmp, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffu), ovf, st);
         return 0;
     };
@@ -298,26 +320,26 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
         if (!guess || !overflow)
             return fail("asynchronous / captured call without a size estimate: run one default (waiting) call with the same "
                         "view configuration first");
-        if (front(nullptr, guess, overflow) || rest(guess)) return 1;
+        if (front(nullptr, 0u, guess, overflow) || rest(guess)) return 1;
         *num_rendered = (int)guess;  // the capacity: an upper bound the backward accepts in R's place
         DMR_HIP(hipGetLastError());
         return 0;
     }
     SizeRead* sr = size_read();
-    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
-    int* host_R = reinterpret_cast<int*>(sr->slot);
-    if (front(host_R, ~0ull, nullptr)) return 1;
-    DMR_HIP(hipEventRecord(sr->ev, st));
+    if (!sr) return fail("hipHostMalloc failed");
+    const uint32_t seq = sr->next_seq();
+    if (front(const_cast<unsigned long long*>(sr->word(0)), seq, ~0ull, nullptr)) return 1;
     if (guess && rest(guess)) return 1;
-    DMR_HIP(hipEventSynchronize(sr->ev));  // the forward's one host wait (rasterizer_impl.cu:287-292): 4 bytes
-    const int R = *host_R;
-    if (R < 0) return fail("num_rendered overflows 31 bits");
+    unsigned long long R64 = 0;
+    if (wait_size(sr->word(0), seq, st, &R64)) return 1;  // the forward's one host wait (rasterizer_impl.cu:287-292)
+    if (R64 > 0x7fffffffull) return fail("num_rendered overflows 31 bits");
+    const int R = (int)R64;
     *num_rendered = R;
     if (!guess) {
         if (rest((uint64_t)R)) return 1;
     } else if ((uint64_t)R > guess) {  // the guess was too small: redo binning + render with the exact size
         DMR_HIP(hipStreamSynchronize(st));
-        if (front(nullptr, ~0ull, nullptr) || rest((uint64_t)R)) return 1;
+        if (front(nullptr, 0u, ~0ull, nullptr) || rest((uint64_t)R)) return 1;
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
@@ -495,7 +517,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
         return 0;
     };
-    const dmr::HitRegions scanned{nullptr, nullptr, nullptr, nullptr};
+    const dmr::HitRegions scanned{nullptr, nullptr, nullptr, nullptr, 0u};
     // With a size estimate and few enough tiles the per-pixel kernel lays the regions out itself: no scan launch.
     const bool self_regions = d.ntiles <= dmr::SCAN_SINGLE_MAX;
     const SizeKey key = size_key(s, false, d);
@@ -511,35 +533,34 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
             return fail("asynchronous / captured call without a size estimate: run one default (waiting) backward with the "
                         "same view configuration first");
         if (self_regions) {
-            if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, overflow}, nullptr)) return 1;
+            if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, overflow, 0u}, nullptr)) return 1;
         } else {
-            dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, nullptr, is.scan_tmp, (uint32_t)guess, overflow, st);
+            dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, nullptr, 0u, is.scan_tmp, (uint32_t)guess, overflow, st);
             if (rest(guess, scanned, nullptr)) return 1;
         }
         DMR_HIP(hipGetLastError());
         return 0;
     }
     SizeRead* sr = size_read();
-    if (!sr) return fail("hipHostMalloc / hipEventCreate failed");
-    unsigned long long* host_total = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sr->slot) + 8);
-    auto record = [&]() -> int { DMR_HIP(hipEventRecord(sr->ev, st)); return 0; };
+    if (!sr) return fail("hipHostMalloc failed");
+    unsigned long long* host_total = const_cast<unsigned long long*>(sr->word(1));
+    const uint32_t seq = sr->next_seq();
     if (guess && self_regions) {
         // everything is enqueued with the estimate; the total arrives behind the per-pixel kernel
-        if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, host_total, nullptr}, record)) return 1;
+        if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, host_total, nullptr, seq}, nullptr)) return 1;
     } else {
-        dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, host_total, is.scan_tmp, 0xffffffffu, nullptr, st);
-        if (record()) return 1;
+        dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, host_total, seq, is.scan_tmp, 0xffffffffu, nullptr, st);
         if (guess && rest(guess, scanned, nullptr)) return 1;
     }
-    DMR_HIP(hipEventSynchronize(sr->ev));
-    const unsigned long long nhits = *host_total;
+    unsigned long long nhits = 0;
+    if (wait_size(sr->word(1), seq, st, &nhits)) return 1;
     if (nhits >= 0xffffffffull) return fail("more than 2^32 blended (pixel, face) pairs");
     if (!guess) {
         if (rest(nhits, scanned, nullptr)) return 1;
     } else if (nhits > guess) {  // (the redo pass does not store into the pinned slot: a later call may own it by then)
         DMR_HIP(hipStreamSynchronize(st));
         if (self_regions) {
-            if (rest(nhits, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, nullptr}, nullptr)) return 1;
+            if (rest(nhits, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, nullptr, 0u}, nullptr)) return 1;
         } else if (rest(nhits, scanned, nullptr)) return 1;
     }
     {

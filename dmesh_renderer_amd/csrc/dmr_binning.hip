@@ -388,8 +388,8 @@ __device__ __forceinline__ void slab_write_offsets(uint32_t* __restrict__ slab, 
 
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-             uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered, int* __restrict__ host_num_rendered,
-             uint32_t* __restrict__ tile_order, uint32_t capacity, uint32_t* __restrict__ overflow) {
+             uint32_t* __restrict__ tile_cursor, int* __restrict__ num_rendered, unsigned long long* __restrict__ host_num_rendered,
+             uint32_t host_seq, uint32_t* __restrict__ tile_order, uint32_t capacity, uint32_t* __restrict__ overflow) {
     static_assert(ORDER_CELLS == 1024, "one counter cell per thread");
     __shared__ uint32_t wave_sum[17];
     __shared__ uint32_t bucket[ORDER_CELLS + 1];
@@ -440,7 +440,7 @@ k_scan_tiles(int n, const uint32_t* __restrict__ tile_count, uint32_t* __restric
     // host_num_rendered: pinned host memory, read by the host after the event recorded behind this kernel
     if (tid == 0) {
         tile_offset[n] = total; *num_rendered = (int)total;
-        if (host_num_rendered) *host_num_rendered = (int)total;
+        if (host_num_rendered) *host_num_rendered = host_size_word(host_seq, total);  // ONE 8-byte store: the host polls it
         if (overflow && total > capacity) *overflow = 1u;  // asynchronous call that outgrew its buffer (sticky, pinned host memory)
     }
 }
@@ -495,8 +495,8 @@ k_scan_tiles_partial(int n, const uint32_t* __restrict__ tile_count, const uint3
 // (bucket 0 = longest lists first, empty tiles last): the cursors pass 3 claims from
 __global__ void __launch_bounds__(1024)
 k_scan_tiles_blocks(int nblk, int n, uint32_t* __restrict__ blk_sum, uint32_t* __restrict__ bucket_count,
-                    uint32_t* __restrict__ tile_offset, int* __restrict__ num_rendered, int* __restrict__ host_num_rendered,
-                    unsigned long long* __restrict__ total64, unsigned long long* __restrict__ host_total64,
+                    uint32_t* __restrict__ tile_offset, int* __restrict__ num_rendered, unsigned long long* __restrict__ host_num_rendered,
+                    unsigned long long* __restrict__ total64, unsigned long long* __restrict__ host_total64, uint32_t host_seq,
                     uint32_t capacity, uint32_t* __restrict__ overflow) {
     __shared__ uint32_t wave_sum[17];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -510,8 +510,8 @@ k_scan_tiles_blocks(int nblk, int n, uint32_t* __restrict__ blk_sum, uint32_t* _
     }
     if (tid == 0) {
         tile_offset[n] = (uint32_t)carry;
-        if (num_rendered) { *num_rendered = (int)carry; if (host_num_rendered) *host_num_rendered = (int)carry; }
-        if (total64) { *total64 = carry; if (host_total64) *host_total64 = carry; }
+        if (num_rendered) { *num_rendered = (int)carry; if (host_num_rendered) *host_num_rendered = host_size_word(host_seq, carry); }
+        if (total64) { *total64 = carry; if (host_total64) *host_total64 = host_size_word(host_seq, carry); }
         if (overflow && carry > (unsigned long long)capacity) *overflow = 1u;
     }
     if (bucket_count && tid < 128) {  // waves 0 and 1; only wave 0 holds buckets 0..63, the empty-tile bucket follows them
@@ -597,7 +597,7 @@ k_scan_tiles_final(int n, const uint32_t* __restrict__ tile_count, const uint32_
 // the backward fails) and the total.  Also clears tile_used (records the per-pixel kernel really wrote, per tile).
 __global__ void __launch_bounds__(1024)
 k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ hit_offset,
-            uint32_t* __restrict__ tile_used, unsigned long long* __restrict__ hit_total, unsigned long long* __restrict__ host_hit_total,
+            uint32_t* __restrict__ tile_used, unsigned long long* __restrict__ hit_total, unsigned long long* __restrict__ host_hit_total, uint32_t host_seq,
             uint32_t capacity, uint32_t* __restrict__ overflow) {
     __shared__ uint32_t wave_sum[17];
     __shared__ unsigned long long s_total;
@@ -627,7 +627,7 @@ k_scan_hits(int n, const uint32_t* __restrict__ tile_hits, const uint32_t* __res
     for (int j = 0; j < SCAN_BATCH; j++) { const int i = j * 1024 + tid; if (i < n) hit_offset[i] = slab[i]; }
     if (tid == 0) {
         hit_offset[n] = wave_sum[16]; *hit_total = s_total;
-        if (host_hit_total) *host_hit_total = s_total;
+        if (host_hit_total) *host_hit_total = host_size_word(host_seq, s_total);
         if (overflow && s_total > (unsigned long long)capacity) *overflow = 1u;
     }
 }
@@ -680,11 +680,11 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
 }
 
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
-                       int* num_rendered, int* host_num_rendered, uint32_t* tile_order, uint32_t* scan_tmp,
+                       int* num_rendered, unsigned long long* host_num_rendered, uint32_t host_seq, uint32_t* tile_order, uint32_t* scan_tmp,
                        uint32_t capacity, uint32_t* overflow, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
     if (ntiles <= SCAN_SINGLE_MAX) {
-        k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered, host_num_rendered, tile_order,
+        k_scan_tiles<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_count, tile_offset, tile_cursor, num_rendered, host_num_rendered, host_seq, tile_order,
                                                     capacity, overflow);
         return;
     }
@@ -694,25 +694,25 @@ void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_of
     uint32_t* blk_sum = scan_tmp + SCAN_TMP_BUCKETS;
     k_scan_tiles_partial<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, nullptr, blk_sum, bucket);
     k_scan_tiles_blocks<<<dim3(1), dim3(1024), 0, st>>>(nblk, ntiles, blk_sum, bucket, tile_offset, num_rendered, host_num_rendered,
-                                                        nullptr, nullptr, capacity, overflow);
+                                                        nullptr, nullptr, host_seq, capacity, overflow);
     k_scan_tiles_final<true><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_count, nullptr, blk_sum, bucket, tile_offset, tile_cursor, tile_order);
 }
 
 size_t scan_tmp_words(int ntiles) { return SCAN_TMP_BUCKETS + (size_t)(ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES + 1; }
 
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, const uint32_t* tile_offset, uint32_t* hit_offset, uint32_t* tile_used,
-                      unsigned long long* hit_total, unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity,
+                      unsigned long long* hit_total, unsigned long long* host_hit_total, uint32_t host_seq, uint32_t* scan_tmp, uint32_t capacity,
                       uint32_t* overflow, hipStream_t st) {
     StageScope t(DMR_STAGE_SCAN, st);
     if (ntiles <= SCAN_SINGLE_MAX) {
-        k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, tile_offset, hit_offset, tile_used, hit_total, host_hit_total, capacity, overflow);
+        k_scan_hits<<<dim3(1), dim3(1024), 0, st>>>(ntiles, tile_hits, tile_offset, hit_offset, tile_used, hit_total, host_hit_total, host_seq, capacity, overflow);
         return;
     }
     const int nblk = (ntiles + SCAN_BLOCK_TILES - 1) / SCAN_BLOCK_TILES;
     uint32_t* blk_sum = scan_tmp + SCAN_TMP_BUCKETS;  // the forward's partial sums are no longer needed
     k_scan_tiles_partial<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, tile_offset, blk_sum, nullptr);
     k_scan_tiles_blocks<<<dim3(1), dim3(1024), 0, st>>>(nblk, ntiles, blk_sum, nullptr, hit_offset, nullptr, nullptr, hit_total,
-                                                        host_hit_total, capacity, overflow);
+                                                        host_hit_total, host_seq, capacity, overflow);
     k_scan_tiles_final<false><<<dim3(nblk), dim3(1024), 0, st>>>(ntiles, tile_hits, tile_offset, blk_sum, nullptr, hit_offset, tile_used, nullptr);
 }
 

@@ -57,10 +57,17 @@ void launch_setup_faces(const dmr_scene& s, bool tet, const float4* vproj, int g
 // scan_tmp: scan_tmp_words(ntiles) u32 of scratch whose first SCAN_TMP_BUCKETS words are zero on entry
 constexpr int SCAN_TMP_BUCKETS = 128;
 size_t scan_tmp_words(int ntiles);
-// host_num_rendered (pinned, may be null): receives R.  overflow (pinned, may be null): set to 1 when R > capacity
-// (asynchronous calls, which never read R on the host)
+// A size the host waits for travels as ONE 8-byte word in pinned (coherent) host memory: the call's sequence number in the
+// top 24 bits, the size (clamped to 40 bits) below.  The host polls the word until the sequence number is its own: no event
+// packet in the stream (an event record between two kernels costs the device 2-7 us, profiles/r03/dead_ends.md), no ordering
+// question between a value and a flag.
+__host__ __device__ inline unsigned long long host_size_word(uint32_t seq, unsigned long long size) {
+    return ((unsigned long long)(seq & 0xffffffu) << 40) | (size < (1ull << 40) ? size : (1ull << 40) - 1ull);
+}
+// host_num_rendered (pinned, may be null): receives host_size_word(host_seq, R).  overflow (pinned, may be null): set to 1 when
+// R > capacity (asynchronous calls, which never read R on the host)
 void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor,
-                       int* num_rendered, int* host_num_rendered, uint32_t* tile_order, uint32_t* scan_tmp,
+                       int* num_rendered, unsigned long long* host_num_rendered, uint32_t host_seq, uint32_t* tile_order, uint32_t* scan_tmp,
                        uint32_t capacity, uint32_t* overflow, hipStream_t st);
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
                           const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
@@ -99,7 +106,7 @@ void launch_tri_forward(const dmr_scene& s, int gx, int gy, int r0, int r1, cons
 // hit_offset: every tile's region of the record buffer, sized by the bound h + (HIT_GROUP - 1) * min(list length, h) of
 // its h blended pairs (tile_hits); tile_used is cleared (the per-pixel kernel fills it)
 void launch_scan_hits(int ntiles, const uint32_t* tile_hits, const uint32_t* tile_offset, uint32_t* hit_offset, uint32_t* tile_used,
-                      unsigned long long* hit_total, unsigned long long* host_hit_total, uint32_t* scan_tmp, uint32_t capacity,
+                      unsigned long long* hit_total, unsigned long long* host_hit_total, uint32_t host_seq, uint32_t* scan_tmp, uint32_t capacity,
                       uint32_t* overflow, hipStream_t st);
 // Without launch_scan_hits (B * tiles <= SCAN_SINGLE_MAX): every workgroup of k_tri_backward_pix sums the record bounds of
 // the tiles before its own (tile_bound: eight 16-byte loads per thread, all in flight at once) and publishes hit_offset[tile] /
@@ -108,6 +115,7 @@ void launch_scan_hits(int ntiles, const uint32_t* tile_hits, const uint32_t* til
 struct HitRegions {
     uint32_t* hit_offset;                 // null: the regions come from launch_scan_hits
     unsigned long long* hit_total; unsigned long long* host_hit_total; uint32_t* overflow;  // the last two may be null
+    uint32_t host_seq;                    // host_hit_total receives host_size_word(host_seq, total)
 };
 // also zeroes work[0, work_floats) (the packed accumulators)
 void launch_tri_backward_pix(const dmr_scene& s, int gx, int gy, int r0, int r1, const float4* vproj,

@@ -559,7 +559,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
             if (tid == 0) {
                 const unsigned long long total = s_before[0] + s_before[1] + s_before[2] + s_before[3];
                 *regions.hit_total = total;
-                if (regions.host_hit_total) *regions.host_hit_total = total;
+                if (regions.host_hit_total) *regions.host_hit_total = host_size_word(regions.host_seq, total);
                 if (regions.overflow && total > (unsigned long long)capacity) *regions.overflow = 1u;
                 p.tile_used[tile] = 0u;
             }
@@ -618,7 +618,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
             if (last) {
                 const unsigned long long all = before + p.tile_bound[tile];
                 *regions.hit_total = all;
-                if (regions.host_hit_total) *regions.host_hit_total = all;
+                if (regions.host_hit_total) *regions.host_hit_total = host_size_word(regions.host_seq, all);
                 if (regions.overflow && all > (unsigned long long)capacity) *regions.overflow = 1u;
             }
             if (total == 0) p.tile_used[tile] = 0u;  // (cannot happen for a tile with blended pairs; published all the same)

@@ -94,8 +94,9 @@ typedef struct dmr_scene {
  * face) pairs (the tri backward's record buffer) are results of kernels.  The reference stalls on a device->host copy of
  * R before it can go on (rasterizer_impl.cu:287-299).  Here a call sizes both buffers from the previous call with the
  * same view configuration (+25 %), enqueues everything, and
- *   - by default waits on an event behind the scan kernel (which writes the size to pinned memory) -- the GPU keeps
- *     running -- returns the exact R and redoes the affected stages if the estimate was too small;
+ *   - by default waits for the size to arrive in pinned host memory (the kernel that computes it stores it there; the host
+ *     polls the word: no event, no stream synchronisation, the GPU keeps running), returns the exact R and redoes the
+ *     affected stages if the estimate was too small;
  *   - with DMR_FLAG_ASYNC, or when `stream` is being captured into a HIP graph (hipStreamIsCapturing), does not wait at
  *     all: *num_rendered receives the CAPACITY it used (an upper bound that the backward accepts in R's place), every
  *     kernel clamps to it, and a scene that outgrew it sets a sticky per-device flag that dmr_overflowed() reports --
