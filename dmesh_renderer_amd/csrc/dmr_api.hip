@@ -225,7 +225,7 @@ bool stream_is_capturing(hipStream_t st) {
 // never wait: the size is not read back at all, the scan kernel compares it with the capacity on the device and sets
 // the sticky overflow word (dmr_overflowed).  That is what makes forward + backward capturable as one graph.
 struct SizeKey {
-    int v[6];
+    int v[7];
     bool operator<(const SizeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
 // seq_steps: tet only -- pinned word the backward kernels leave the forward's longest march in (steps); read without any
@@ -233,8 +233,23 @@ struct SizeKey {
 struct SizeGuess { double rendered_per_face = 0.0, hits_per_face = 0.0; uint32_t* seq_steps = nullptr; };
 std::mutex g_size_mu;
 std::map<SizeKey, SizeGuess> g_size_cache;
+// ... and by the magnitude of the mesh (floor(log2(B * F))): two renderers with the same view configuration and meshes of very
+// different size -- say a coarse and a fine level of one pipeline, alternating -- would otherwise trade one entry back and forth
+// between over-allocation and the redo path ("what's weak" 8).  A mesh that crosses a power of two finds the
+// neighbouring bucket's estimate (lookup tries b, b - 1, b + 1).
+std::atomic<uint64_t> g_redo_count{0};  // stages enqueued a second time because an estimate was too small (dmr_redo_count)
+int size_bucket(size_t BF) { int b = 0; while ((BF >> (b + 1)) != 0) b++; return b; }
 SizeKey size_key(const dmr_scene* s, bool tet, const Dims& d) {
-    return SizeKey{{s->B, s->W, s->H, d.r0, d.r1, tet ? 1 : 0}};
+    return SizeKey{{s->B, s->W, s->H, d.r0, d.r1, tet ? 1 : 0, size_bucket(d.BF)}};
+}
+// the estimate `field` of this key's bucket or, failing that, of a neighbouring bucket (0: none); g_size_mu held
+double lookup_estimate(const SizeKey& key, double SizeGuess::* field) {
+    for (int db : {0, -1, 1}) {
+        SizeKey k = key; k.v[6] += db;
+        auto it = g_size_cache.find(k);
+        if (it != g_size_cache.end() && it->second.*field > 0.0) return it->second.*field;
+    }
+    return 0.0;
 }
 uint64_t padded(uint64_t n) { return n + n / 4 + 4096; }
 
@@ -312,9 +327,8 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     uint64_t guess = 0;
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
-        auto it = g_size_cache.find(key);
-        if (it != g_size_cache.end() && it->second.rendered_per_face > 0.0)
-            guess = std::min<uint64_t>(padded((uint64_t)(it->second.rendered_per_face * (double)d.BF)), 0x7fffffffu);
+        const double per_face = lookup_estimate(key, &SizeGuess::rendered_per_face);
+        if (per_face > 0.0) guess = std::min<uint64_t>(padded((uint64_t)(per_face * (double)d.BF)), 0x7fffffffu);
     }
     if (async) {  // no host wait at all: capacity from the estimate, overflow checked on the device
         if (!guess || !overflow)
@@ -338,6 +352,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
     if (!guess) {
         if (rest((uint64_t)R)) return 1;
     } else if ((uint64_t)R > guess) {  // the guess was too small: redo binning + render with the exact size
+        g_redo_count.fetch_add(1, std::memory_order_relaxed);
         DMR_HIP(hipStreamSynchronize(st));
         if (front(nullptr, 0u, ~0ull, nullptr) || rest((uint64_t)R)) return 1;
     }
@@ -428,6 +443,7 @@ int dmr_overflowed(int device, int reset) {
     if (reset) *v = 0u;
     return r;
 }
+uint64_t dmr_redo_count(void) { return g_redo_count.load(std::memory_order_relaxed); }
 int dmr_abi_version(void) { return DMR_ABI_VERSION; }
 const char* dmr_build_arch(void) { return "gfx950"; }
 
@@ -524,9 +540,8 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     uint64_t guess = 0;
     {
         std::lock_guard<std::mutex> lk(g_size_mu);
-        auto it = g_size_cache.find(key);
-        if (it != g_size_cache.end() && it->second.hits_per_face > 0.0)
-            guess = std::min<uint64_t>(padded((uint64_t)(it->second.hits_per_face * (double)d.BF)), 0xfffffffeull);
+        const double per_face = lookup_estimate(key, &SizeGuess::hits_per_face);
+        if (per_face > 0.0) guess = std::min<uint64_t>(padded((uint64_t)(per_face * (double)d.BF)), 0xfffffffeull);
     }
     if (async) {  // no host wait: see run_forward
         if (!guess || !overflow)
@@ -558,6 +573,7 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     if (!guess) {
         if (rest(nhits, scanned, nullptr)) return 1;
     } else if (nhits > guess) {  // (the redo pass does not store into the pinned slot: a later call may own it by then)
+        g_redo_count.fetch_add(1, std::memory_order_relaxed);
         DMR_HIP(hipStreamSynchronize(st));
         if (self_regions) {
             if (rest(nhits, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, nullptr, 0u}, nullptr)) return 1;

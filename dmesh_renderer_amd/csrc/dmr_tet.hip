@@ -11,6 +11,7 @@
 // forward.cu:90-145; seeded jitter from a counter-based generator, dmr_device.hpp).
 // Guards: Q17 (no work when P/F/T == 0), Q18 (only pixels inside the image are touched),
 // Q19 (the unread is_active_backward diagnostic is dropped).
+#include <algorithm>
 #include <cstdlib>
 
 #include "dmr_kernels.hpp"
@@ -707,8 +708,11 @@ __device__ __forceinline__ bool tet_bwd_begin(const TetParams& p, int b, int px,
 // The re-marching backward (the reference's algorithm): the fallback when the forward's march sequence is not there --
 // no capacity estimate yet (first call of a view configuration) or a scene that outgrew it.  Decided on the device:
 // both kernels are always launched and one of them returns at once.
+// (Launched with a few workgroups per CU that loop over the band's tiles, not one per tile: when it is the idle one of the
+// two launches -- every call but the first of a view configuration -- 2 500 workgroups that only find that out cost 6.7 us
+// at C3, 768 cost under 2.)
 __global__ void __launch_bounds__(256)
-k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+k_tet_backward(TetParams p, int rows, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                float* __restrict__ dL_dvcolor, float* __restrict__ dL_dfopacity) {
     {
         const uint32_t cap = p.img.seq->cap_steps;
@@ -717,54 +721,57 @@ k_tet_backward(TetParams p, const float* __restrict__ dL_dcolor, const float* __
     __shared__ int s_key[TET_TBL];
     __shared__ double s_val[10][TET_TBL];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < TET_TBL; i += 256) {
-        s_key[i] = -1;
-#pragma unroll
-        for (int c = 0; c < 10; c++) s_val[c][i] = 0.0;
-    }
-    __syncthreads();
     const TetAccum acc{s_key, s_val};
-
-    const int tx = blockIdx.x, ty = blockIdx.y + p.r0, b = blockIdx.z;
-    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
-    TetBwdPixel st;
-    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
-    int first_face = -1, last_face = -1;
-    bool done = !tet_bwd_begin(p, b, px, py, dL_dcolor, dL_ddepth, st, ro, rd, first_face, last_face);
-    const float* mv = p.mv + 16 * b;
-    const float* pr = p.proj + 16 * b;
-    int curr_face = last_face, curr_tet = -1, curr_slot = 0;
-    float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
-    V3 curr_n = {0, 0, 0};
-    if (!done) {
-        curr_tet = p.img.last_tet[(int64_t)b * p.H * p.W + (int64_t)p.W * py + px];
-        face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv, curr_n);
-        // step back across the last face (backward.cu:223-232)
-        for (int i = 0; i < 2; i++) {
-            const int t = p.face_tets[2 * curr_face + i];
-            if (t == curr_tet) continue;
-            curr_tet = t;
-            break;
+    const int ntiles = p.gx * rows * p.B;
+    for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {   // tiles of the band [r0, r0 + rows), all views
+        __syncthreads();  // (the previous tile's flush has read the table)
+        for (int i = tid; i < TET_TBL; i += 256) {
+            s_key[i] = -1;
+#pragma unroll
+            for (int c = 0; c < 10; c++) s_val[c][i] = 0.0;
         }
-        if (curr_tet >= 0) curr_slot = tet_slot_of(p.tetrec, curr_tet, curr_face);
-    }
-    while (!__all(done)) {  // the wave's lanes stay together: tet_accumulate merges lanes that hold the same face
-        const bool act = !done;
-        float g[10];
-        int v0 = 0, v1 = 0, v2 = 0;
-        const int face = curr_face;
-        if (act) {
-            st.face_grad(p, b, curr_face, ro, rd, mv, pr, curr_rt, curr_iu, curr_iv, g, v0, v1, v2);
-            if (curr_face == first_face) done = true;
-            if (!done) {
-                if (curr_tet == -1) done = true;
-                else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
+        __syncthreads();
+        const int tx = ti % p.gx, ty = (ti / p.gx) % rows + p.r0, b = ti / (p.gx * rows);
+        const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+        TetBwdPixel st;
+        V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+        int first_face = -1, last_face = -1;
+        bool done = !tet_bwd_begin(p, b, px, py, dL_dcolor, dL_ddepth, st, ro, rd, first_face, last_face);
+        const float* mv = p.mv + 16 * b;
+        const float* pr = p.proj + 16 * b;
+        int curr_face = last_face, curr_tet = -1, curr_slot = 0;
+        float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
+        V3 curr_n = {0, 0, 0};
+        if (!done) {
+            curr_tet = p.img.last_tet[(int64_t)b * p.H * p.W + (int64_t)p.W * py + px];
+            face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv, curr_n);
+            // step back across the last face (backward.cu:223-232)
+            for (int i = 0; i < 2; i++) {
+                const int t = p.face_tets[2 * curr_face + i];
+                if (t == curr_tet) continue;
+                curr_tet = t;
+                break;
             }
+            if (curr_tet >= 0) curr_slot = tet_slot_of(p.tetrec, curr_tet, curr_face);
         }
-        tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
+        while (!__all(done)) {  // the wave's lanes stay together: tet_accumulate merges lanes that hold the same face
+            const bool act = !done;
+            float g[10];
+            int v0 = 0, v1 = 0, v2 = 0;
+            const int face = curr_face;
+            if (act) {
+                st.face_grad(p, b, curr_face, ro, rd, mv, pr, curr_rt, curr_iu, curr_iv, g, v0, v1, v2);
+                if (curr_face == first_face) done = true;
+                if (!done) {
+                    if (curr_tet == -1) done = true;
+                    else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
+                }
+            }
+            tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
+        }
+        __syncthreads();
+        tet_flush(p, s_key, s_val, tid, dL_dvcolor, dL_dfopacity);
     }
-    __syncthreads();
-    tet_flush(p, s_key, s_val, tid, dL_dvcolor, dL_dfopacity);
 }
 
 // The backward on the forward's march sequence (dmr_kernels.hpp): a wave walks its rows from the back, step s of all its
@@ -935,7 +942,8 @@ void launch_tet_backward(const dmr_scene& s, int gx, int gy, int r0, int r1, Tet
     TetParams p = make_params(s, gx, gy, r0, img);
     StageScope t(DMR_STAGE_TET_BACKWARD, st);
     k_tet_backward_seq<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity, host_seq_steps);
-    k_tet_backward<<<dim3(gx, r1 - r0, s.B), dim3(256), 0, st>>>(p, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity);
+    const int ntiles = gx * (r1 - r0) * s.B;
+    k_tet_backward<<<dim3((unsigned)std::min(ntiles, 768)), dim3(256), 0, st>>>(p, r1 - r0, dL_dcolor, dL_ddepth, dL_dvcolor, dL_dfopacity);
 }
 
 }  // namespace dmr

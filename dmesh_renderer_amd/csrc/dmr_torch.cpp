@@ -58,6 +58,7 @@ struct Abi {
     decltype(&dmr_stage_name) stage_name = nullptr;
     decltype(&dmr_last_error) last_error = nullptr;
     decltype(&dmr_overflowed) overflowed = nullptr;
+    decltype(&dmr_redo_count) redo_count = nullptr;
     decltype(&dmr_abi_version) abi_version = nullptr;
     decltype(&dmr_build_arch) build_arch = nullptr;
 };
@@ -94,7 +95,7 @@ void load_abi() {
     bind(g_abi.invert_mats, "dmr_invert_mats"); bind(g_abi.export_item, "dmr_export");
     bind(g_abi.profile_enable, "dmr_profile_enable"); bind(g_abi.profile_collect, "dmr_profile_collect");
     bind(g_abi.stage_name, "dmr_stage_name"); bind(g_abi.last_error, "dmr_last_error");
-    bind(g_abi.overflowed, "dmr_overflowed"); bind(g_abi.abi_version, "dmr_abi_version");
+    bind(g_abi.overflowed, "dmr_overflowed"); bind(g_abi.redo_count, "dmr_redo_count"); bind(g_abi.abi_version, "dmr_abi_version");
     bind(g_abi.build_arch, "dmr_build_arch");
     if (g_abi.abi_version() != DMR_ABI_VERSION)
         throw std::runtime_error("ABI mismatch: " + path + " is version " + std::to_string(g_abi.abi_version()) +
@@ -464,6 +465,8 @@ PYBIND11_MODULE(_C, m) {
     m.def("set_async", [](bool on) { g_async.store(on ? 1 : 0); }, py::arg("on"),
           "Calls never wait for the device: num_rendered is the capacity used; check overflowed() after synchronising.");
     m.def("is_async", []() { return g_async.load() != 0; });
+    m.def("redo_count", []() { return (unsigned long long)g_abi.redo_count(); },
+          "Default calls that had to enqueue stages twice because a size estimate was too small (process-wide).");
     m.def("overflowed", [](int device, bool reset) { return g_abi.overflowed(device, reset ? 1 : 0) != 0; }, py::arg("device") = -1,
           py::arg("reset") = true, "True if an asynchronous / graph-captured call outgrew its buffers since the last reset.");
     // per-stage HIP-event timing (bench.py's roofline leg)

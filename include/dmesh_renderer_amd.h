@@ -107,6 +107,10 @@ typedef struct dmr_scene {
 /* 1 if an asynchronous / captured call on `device` (-1: the current one) overflowed its capacity since the flag was
  * last reset; call it after the stream (or the graph launch) has completed.  reset != 0 clears the flag. */
 int dmr_overflowed(int device, int reset);
+/* How often a default call had to enqueue stages a second time because its size estimate was too small (process-wide,
+ * monotonic): 0 in a steady training loop; a figure that keeps growing says the estimates do not fit the workload (they are
+ * kept per view configuration and power-of-two bucket of B * F). */
+uint64_t dmr_redo_count(void);
 
 /* out_color [B,3,H,W], out_depth [B,1,H,W]: every pixel of the rendered tile rows is written; the caller
  * zero-initialises them (render.cu:88-89) when a band leaves rows untouched or when P == 0 / F == 0

@@ -47,6 +47,7 @@ EXPORTS = {
     "dmr_export": (C.c_int64, [C.POINTER(Scene), C.c_int, C.c_int, C.c_char_p] + [C.c_void_p] * 4
                    + [C.c_void_p, C.c_int64, C.c_void_p]),
     "dmr_invert_mats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dmr_redo_count": (C.c_uint64, []),
     "dmr_profile_enable": (None, [C.c_uint32]),
     "dmr_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dmr_stage_name": (C.c_char_p, [C.c_int]),

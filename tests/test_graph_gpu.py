@@ -246,3 +246,31 @@ def test_capture_on_an_empty_band(hip_device):
     th.cuda.synchronize()
     assert not _C.overflowed()
     assert all(float(t.abs().sum()) == 0.0 for t in grads)
+
+
+def test_two_meshes_of_one_view_configuration_do_not_trade_estimates(hip_device, oracle):
+    """Two renderers with the same (B, W, H) and meshes of very different size, called alternately (a coarse and a fine level
+    of one pipeline): the size estimates are kept per view configuration AND power-of-two bucket of B * F, so after each mesh's
+    first step no call has to enqueue its stages twice (`_C.redo_count()`; VERDICT r02 "what's weak" 8) -- and every result is
+    still the oracle's."""
+    from dmesh_renderer_amd import _C
+    dev = hip_device
+    B, H, W = 1, 216, 344
+    gc, gd = upstream_grads(B, H, W)
+    gcd, gdd = gc.to(dev), gd.to(dev)
+    coarse = scenes.layered_sheets(2, 6, B, H, W, seed=1)        # 100 faces, each over many tiles: many entries per face
+    fine = scenes.layered_sheets(6, 40, B, H, W, seed=2)         # 18 252 small faces: few entries per face
+    meshes = [(coarse, c_args(coarse, dev), _oracle_tri(oracle, coarse, H, W, gc, gd)),
+              (fine, c_args(fine, dev), _oracle_tri(oracle, fine, H, W, gc, gd))]
+    assert fine["faces"].shape[0] > 64 * coarse["faces"].shape[0]
+    redo = []
+    for it in range(6):
+        for d, args, (oc, od, og) in meshes:
+            o = _C.render_tris(*args, H, W)
+            g = _C.render_tris_backward(*args, gcd, gdd, o[0], *o[3:7])
+            th.cuda.synchronize()
+            assert np.abs(o[1].cpu().numpy() - oc).max() <= FWD_TOL
+            for a, k in zip(g, TRI_NAMES):
+                assert rel_err(a.cpu().numpy(), og[k]) <= GRAD_TOL, (it, k)
+        redo.append(_C.redo_count())
+    assert redo[-1] == redo[0], redo  # nothing was enqueued twice after the first round
