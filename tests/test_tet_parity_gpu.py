@@ -124,16 +124,15 @@ def test_backward_on_the_march_sequence(oracle, hip_device, case):
 
 
 def test_march_sequence_overflow_falls_back(oracle, hip_device):
-    """A scene that outgrows the sequence capacity estimated from the previous call (the same view configuration, first a
-    mesh that covers a corner of the image, then one that fills it): the forward's sequence is incomplete, the device-side
-    check hands the backward to the re-marching kernel, and the gradients are still the oracle's."""
+    """A step whose marches outgrow the sequence capacity estimated from the previous call (the same mesh and view configuration,
+    first nearly opaque -- every ray stops after a few faces --, then nearly transparent): the forward's sequence is incomplete,
+    the device-side check hands the backward to the re-marching kernel, and the gradients are still the oracle's."""
     from dmesh_renderer_amd import _C
     B, H, W = 1, 208, 304
     gc, gd = upstream_grads(B, H, W)
     seen = []
-    for m, scale in ((3, 0.15), (3, 0.15), (7, 1.0), (7, 1.0)):
-        d = scenes.kuhn_tets(m, B, H, W, seed=0, opacity=(0.02, 0.2))
-        d["verts"] = d["verts"] * scale
+    for opacity in ((0.85, 0.95), (0.85, 0.95), (0.02, 0.2), (0.02, 0.2)):
+        d = scenes.kuhn_tets(7, B, H, W, seed=0, opacity=opacity)
         sc = oracle.scene_from_module_inputs(d, H, W)
         _, _, _, ost = oracle.tet_forward(sc)
         og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
@@ -142,10 +141,11 @@ def test_march_sequence_overflow_falls_back(oracle, hip_device):
         g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *out[3:7])
         th.cuda.synchronize()
         seen.append(_seq_state(_C, args, out[3:7], H, W))
+        assert seen[-1][0] == int(ost.get("n_contrib").max())
         for got, key in zip(g, ("verts_color", "faces_opacity")):
-            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (m, key)
+            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (opacity, key)
     assert seen[0][1] == 0 and 0 < seen[1][0] <= seen[1][1], seen   # no estimate, then a complete sequence
-    assert seen[2][0] > seen[2][1] > 0, seen                         # the big mesh after the small one: overflow -> re-march
+    assert seen[2][0] > seen[2][1] > 0, seen                         # long marches after short ones: overflow -> re-march
     assert 0 < seen[3][0] <= seen[3][1], seen                        # ... and the estimate has caught up
 
 

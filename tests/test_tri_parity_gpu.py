@@ -166,6 +166,7 @@ def test_size_guess_is_refuted_and_redone(oracle, hip_device):
     L, n, B, H, W = 3, 14, 1, 160, 160
     gc, gd = upstream_grads(B, H, W)
     rs = []
+    redo0 = _C.redo_count()
     for scale in (0.12, 1.0, 0.3, 1.0):
         d = scenes.layered_sheets(L, n, B, H, W, seed=7)
         d["verts"] = d["verts"] * scale
@@ -182,6 +183,7 @@ def test_size_guess_is_refuted_and_redone(oracle, hip_device):
         for got, key in zip(g, ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")):
             assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (scale, key)
     assert rs[1] > 1.5 * rs[0], "second scene must exceed the size guess"
+    assert _C.redo_count() >= redo0 + 2, "the refuted guesses must have gone through the redo path (forward and backward)"
 
 
 def test_size_guess_refuted_by_screen_filling_faces(oracle, hip_device):
@@ -202,6 +204,7 @@ def test_size_guess_refuted_by_screen_filling_faces(oracle, hip_device):
     both["verts_depth"] = th.cat([base["verts_depth"], big["verts_depth"]], dim=1)
     both["faces_intense"] = th.cat([base["faces_intense"], big["faces_intense"]], dim=1)
     rs = []
+    redo0 = _C.redo_count()
     for d in (base, both, base, both):
         sc = oracle.scene_from_module_inputs(d, H, W)
         ocolor, odepth, ost = oracle.tri_forward(sc)
@@ -218,6 +221,7 @@ def test_size_guess_refuted_by_screen_filling_faces(oracle, hip_device):
             assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, key
         rs.append(out[0] / d["faces"].shape[0])
     assert rs[1] > 2.0 * rs[0], "the second scene must refute the size guess by a wide margin"
+    assert _C.redo_count() >= redo0 + 2, "the refuted guesses must have gone through the redo path"
 
 
 @pytest.mark.parametrize("scale,rows", [(4.0, (0, 0)), (0.45, (0, 0)), (4.0, (9, 41))])
