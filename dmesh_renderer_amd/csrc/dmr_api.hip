@@ -507,9 +507,8 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     uint32_t* overflow = overflow_word(dev, !async);
     const size_t vbytes = up(sizeof(float) * dmr::VROW * d.BP), fbytes = up(sizeof(float) * dmr::FROW * d.BF);
     const size_t pbytes = up(sizeof(float4) * 2 * (size_t)d.ntiles * dmr::TILE_PIX);  // per tile: its 256 pixels' (ray, upstream gradient) records
-    // regions: see dmr::HitRegions -- null hit_offset: launch_scan_hits has laid the record regions out.  after_pix: called
-    // between the per-pixel and the hit-parallel launch (the event behind which the record total is on the host).
-    auto rest = [&](uint64_t capacity, dmr::HitRegions regions, const std::function<int()>& after_pix) -> int {
+    // regions: see dmr::HitRegions -- null hit_offset: launch_scan_hits has laid the record regions out
+    auto rest = [&](uint64_t capacity, dmr::HitRegions regions) -> int {
         const size_t hbytes = up(sizeof(dmr::HitRecord) * (size_t)capacity);
         char* work = reinterpret_cast<char*>(alloc(ctx, DMR_BUF_WORK, vbytes + fbytes + pbytes + hbytes));
         if (!work) return fail("workspace allocation failed");
@@ -528,7 +527,6 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
         dmr::launch_tri_backward_pix(sc, d.gx, d.gy, d.r0, d.r1, ps.vproj, is.tile_offset, bs.face_list, img,
                                      dL_dcolor, dL_ddepth, pixrec, hits, (uint32_t)capacity,
                                      reinterpret_cast<float*>(work), (vbytes + fbytes) / sizeof(float), regions, st);
-        if (after_pix && after_pix()) return 1;
         dmr::launch_tri_backward_hits(sc, d.gx, d.gy, ps.vproj, bs.face_list, img, pixrec, hits, (uint32_t)capacity, vrow, frow, st);
         dmr::launch_tri_unpack(*s, vrow, frow, dL_dverts, dL_dvcolor, dL_dfopacity, dL_dvdepth, dL_dfintense, st);
         return 0;
@@ -548,10 +546,10 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
             return fail("asynchronous / captured call without a size estimate: run one default (waiting) backward with the "
                         "same view configuration first");
         if (self_regions) {
-            if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, overflow, 0u}, nullptr)) return 1;
+            if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, overflow, 0u})) return 1;
         } else {
             dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, nullptr, 0u, is.scan_tmp, (uint32_t)guess, overflow, st);
-            if (rest(guess, scanned, nullptr)) return 1;
+            if (rest(guess, scanned)) return 1;
         }
         DMR_HIP(hipGetLastError());
         return 0;
@@ -562,22 +560,22 @@ int dmr_tri_backward(const dmr_scene* s, const float* dL_dcolor, const float* dL
     const uint32_t seq = sr->next_seq();
     if (guess && self_regions) {
         // everything is enqueued with the estimate; the total arrives behind the per-pixel kernel
-        if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, host_total, nullptr, seq}, nullptr)) return 1;
+        if (rest(guess, dmr::HitRegions{is.hit_offset, is.hit_total, host_total, nullptr, seq})) return 1;
     } else {
         dmr::launch_scan_hits(d.ntiles, is.tile_hits, is.tile_offset, is.hit_offset, is.tile_used, is.hit_total, host_total, seq, is.scan_tmp, 0xffffffffu, nullptr, st);
-        if (guess && rest(guess, scanned, nullptr)) return 1;
+        if (guess && rest(guess, scanned)) return 1;
     }
     unsigned long long nhits = 0;
     if (wait_size(sr->word(1), seq, st, &nhits)) return 1;
     if (nhits >= 0xffffffffull) return fail("more than 2^32 blended (pixel, face) pairs");
     if (!guess) {
-        if (rest(nhits, scanned, nullptr)) return 1;
+        if (rest(nhits, scanned)) return 1;
     } else if (nhits > guess) {  // (the redo pass does not store into the pinned slot: a later call may own it by then)
         g_redo_count.fetch_add(1, std::memory_order_relaxed);
         DMR_HIP(hipStreamSynchronize(st));
         if (self_regions) {
-            if (rest(nhits, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, nullptr, 0u}, nullptr)) return 1;
-        } else if (rest(nhits, scanned, nullptr)) return 1;
+            if (rest(nhits, dmr::HitRegions{is.hit_offset, is.hit_total, nullptr, nullptr, 0u})) return 1;
+        } else if (rest(nhits, scanned)) return 1;
     }
     {
         std::lock_guard<std::mutex> lk(g_size_mu);

@@ -377,11 +377,8 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     auto seq_put = [&](uint32_t s, int face, bool amb) {  // entry s of this lane
         if (s < seq_cap) reinterpret_cast<uint32_t*>(seq_row + (size_t)(s >> 2) * 64u)[s & 3u] = (uint32_t)face | (amb ? 0x80000000u : 0u);
     };
-#ifndef DMR_TET_SEQ_MODE
-#define DMR_TET_SEQ_MODE 1
-#endif
     while (!done) {
-        if (DMR_TET_SEQ_MODE == 1) seq_put(n_contrib, curr_face, back_amb);
+        seq_put(n_contrib, curr_face, back_amb);
         const float4* cq = reinterpret_cast<const float4*>(p.colrec + curr_face);
         const float4 cq0 = cq[0], cq1 = cq[1], cq2 = cq[2], cq3 = cq[3];
         const V3 c0 = {cq0.x, cq0.y, cq0.z}, c1 = {cq0.w, cq1.x, cq1.y}, c2 = {cq1.z, cq1.w, cq2.x};
@@ -406,7 +403,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         if (curr_tet == -1) { active = true; done = true; }
         if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_n, &back_amb)) done = true;
     }
-    if (DMR_TET_SEQ_MODE != 0) {   // the wave's longest march (complete sequence? the next call's estimate)
+    {   // the wave's longest march (is the sequence complete? the next call's estimate)
         const uint32_t steps = wave_max_u32(n_contrib);
         if (lane == 0 && steps != 0u) atomicMax(&p.img.seq->max_steps, steps);
     }

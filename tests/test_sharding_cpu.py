@@ -136,3 +136,30 @@ def test_band_helpers():
     flat = sharding.flatten_grads(g)
     back = sharding.unflatten_grads(flat, g)
     assert all(th.equal(a, b_) for a, b_ in zip(g, back))
+
+
+def test_band_balance_counts_tiles_as_well_as_list_entries():
+    """`row_work_from_ranges`: a band's cost is its list entries plus a cost per tile (sharding.TILE_COST_ENTRIES, measured at
+    C5: profiles/r03/shard_kernel_sums_c5*.json).  A frame whose entries sit in the middle rows: balanced by entries alone the
+    edge bands get most of the (nearly empty) rows; with the per-tile cost they give rows up, every band still holds work, and
+    the bands still partition the rows."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from dmesh_renderer_amd import sharding
+    B, gy, gx = 2, 64, 48
+    lens = np.zeros((B, gy, gx), dtype=np.int64)
+    lens[:, 24:40, 8:40] = 200            # a dense patch in the middle rows
+    lens[:, :, 20:28] += 3                # a thin column everywhere
+    ends = np.cumsum(lens.reshape(-1))
+    ranges = np.stack([ends - lens.reshape(-1), ends], axis=1)
+    world = 8
+    by_entries = sharding.balanced_bands(sharding.row_work_from_ranges(ranges, B, gy, gx, tile_cost=0.0), world)
+    by_cost = sharding.balanced_bands(sharding.row_work_from_ranges(ranges, B, gy, gx), world)
+    for bands in (by_entries, by_cost):
+        assert bands[0][0] == 0 and bands[-1][1] == gy and all(a[1] == b[0] for a, b in zip(bands[:-1], bands[1:]))
+    rows = lambda bands: [b[1] - b[0] for b in bands]
+    assert rows(by_cost)[0] < rows(by_entries)[0] and rows(by_cost)[-1] < rows(by_entries)[-1]
+    cost = lambda b: lens[:, b[0]:b[1]].sum() + sharding.TILE_COST_ENTRIES * B * gx * (b[1] - b[0])
+    spread = lambda bands: max(cost(b) for b in bands) / (sum(cost(b) for b in bands) / world)
+    assert spread(by_cost) < spread(by_entries)
