@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DMR_ABI_VERSION 3
+#define DMR_ABI_VERSION 4
 
 /* Scratch buffers.  The first four are the reference's pointBuffer / faceBuffer /
  * binningBuffer / imageBuffer (rasterizer.h:14-17): opaque byte buffers that the

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
 
 HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dmesh_renderer_amd")
 LIB_PATH = os.environ.get("DMR_LIBRARY") or os.path.join(HERE, "libdmesh_renderer_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 BUF_POINT, BUF_FACE, BUF_BINNING, BUF_IMAGE, BUF_WORK = range(5)
 NUM_STAGES = 12

@@ -57,7 +57,7 @@ def test_compiled_binding_is_the_only_one():
     from dmesh_renderer_amd import _C
     assert _C.__file__.endswith(".so") and os.path.dirname(_C.__file__) == os.path.dirname(dmr.__file__)
     assert _C.library_path() == os.path.join(os.path.dirname(dmr.__file__), "libdmesh_renderer_hip.so")
-    assert _C.ABI_VERSION == 3 and _C.build_arch() == "gfx950" and _C.NUM_STAGES == 12
+    assert _C.ABI_VERSION == 4 and _C.build_arch() == "gfx950" and _C.NUM_STAGES == 12
     assert _C.stage_name(_C.STAGE_TRI_BACKWARD_HITS) == "k_tri_backward_hits"
     for n in ("render_tris", "render_tris_backward", "render_tets", "render_tets_backward"):  # ext.cpp:6-11
         assert callable(getattr(_C, n))
