@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--stages", action="store_true", help="also print a per-stage timing table to stderr")
     ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed steps before the warm-up, for about this long (0: none)")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous only (gloo, no GPU): prints n_gpus")
+    ap.add_argument("--partition", default="auto", choices=("auto", "bands", "view_bands"),
+                    help="N > 1: tile-row bands of all views, or (view, band) pairs (auto: the latter when B > 1 and N %% B == 0)")
     ap.add_argument("--emulate-rank", default=None, metavar="R/N",
                     help="one process, no collective: time rank R's tile-row band of an N-rank run (for rocprofv3 traces of the per-rank work)")
     return ap.parse_args()
@@ -150,7 +152,8 @@ def main():
 
     from dmesh_renderer_amd import _C, scenes
     from dmesh_renderer_amd.scenes import c_args, max_abs_err, rel_err, upstream_grads
-    from dmesh_renderer_amd.sharding import balanced_bands, row_work_from_ranges
+    from dmesh_renderer_amd.sharding import (SEGMENT_COST_PER_FACE, balanced_bands, row_work_from_ranges, view_row_work_from_ranges,
+                                             view_shares)
 
     cfg = scenes.CONFIGS[a.config]
     tet = cfg.kind == "tet"
@@ -167,7 +170,7 @@ def main():
     gy, gx = (H + 15) // 16, (W + 15) // 16
     GRADS = ("verts_color", "faces_opacity") if tet else ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")
 
-    def forward(rows=(0, 0), fill=True):
+    def forward(rows=(0, 0), fill=True, args=args, B=B):
         """-> (num_rendered, images..., four scratch buffers)"""
         if tet:
             o = _C.render_tets(*args, H, W, 0, rows=rows)
@@ -192,15 +195,55 @@ def main():
     if a.emulate_rank:
         emu = tuple(int(x) for x in a.emulate_rank.split("/"))
         assert world == 1 and 0 <= emu[0] < emu[1]
-    if world > 1 or emu:
-        rows = balanced_bands(row_work_from_ranges(ranges, B, gy, gx), emu[1] if emu else world)[emu[0] if emu else rank]
+    nparts, part = (emu[1], emu[0]) if emu else (world, rank)
+    # (view, band) segments with several views (sharding.view_shares): the rows of all views, view after view, cut into N shares
+    # of equal cost; a rank renders its segments with B = 1 tensors -- it projects, bins and scatters ONE view's faces per call
+    segs = None
+    if (world > 1 or emu) and not tet and B > 1 and a.partition != "bands":
+        segs = view_shares(view_row_work_from_ranges(ranges, B, gy, gx), nparts, SEGMENT_COST_PER_FACE * F)[part]
+        segs = segs or [(0, gy, gy)]  # a rank without rows still steps (and joins the collective): an empty band
+    elif a.partition == "view_bands" and (world > 1 or emu):
+        raise SystemExit("--partition view_bands needs a tri config with B > 1")
+    seg_args = []
+    if segs is not None:
+        for v, r0, r1 in segs:
+            sa = list(args)
+            for i in range(5, 11):  # mv, proj, their inverses, verts_depth, faces_intense: this view's
+                sa[i] = args[i][v:v + 1].contiguous()
+            seg_args.append((v, (r0, r1), sa, gc[v:v + 1].contiguous(), gd[v:v + 1].contiguous()))
+    elif world > 1 or emu:
+        rows = balanced_bands(row_work_from_ranges(ranges, B, gy, gx), nparts)[part]
         if rows[1] <= rows[0]:
             rows = (gy, gy)  # an empty band ((0, 0) would mean "all rows")
     del out, bufs
 
+    # the all-reduce payload: [3P | 3P | F | B*P | B*F] (tet: [3P | F]) of ALL views
     flat = th.empty(3 * P + F if tet else 6 * P + F + B * (P + F), dtype=th.float32, device=dev)
+    flat1 = th.empty(7 * P + 2 * F, dtype=th.float32, device=dev) if segs is not None else None
+
+    def step_segments():
+        """This rank's (view, band) segments, one B = 1 forward + backward each; their gradients into the all-views payload:
+        the shared part summed over the segments, each segment's per-view rows in its view's place, the other views' rows zero
+        (the all-reduce overwrites the payload with the sums: cleared every step)."""
+        sh = 6 * P + F
+        flat[sh:].zero_()
+        o = g = None
+        for i, (v, rws, sa, gcv, gdv) in enumerate(seg_args):
+            o = forward(rws, fill=False, args=sa, B=1)
+            g = _C.render_tris_backward(*sa, gcv, gdv, o[0], *o[-4:], rows=rws, flat_out=flat1)
+            if i == 0:
+                flat[:sh].copy_(flat1[:sh])
+            else:
+                flat[:sh].add_(flat1[:sh])
+            flat[sh + v * P:sh + (v + 1) * P].add_(flat1[sh:sh + P])
+            flat[sh + B * P + v * F:sh + B * P + (v + 1) * F].add_(flat1[sh + P:])
+        if world > 1:
+            dist.all_reduce(flat)
+        return o, g
 
     def step():
+        if segs is not None:
+            return step_segments()
         o = forward(rows, fill=False)  # a rank only owns the rows of its band
         kw = {}
         if world > 1 or emu:  # the gradients land back to back in `flat` (views are returned): ONE collective, no concatenation
@@ -313,7 +356,17 @@ def main():
     #   k_tet_forward / k_tet_backward     : the packed mesh records once + 4 B per marched pair S (the march sequence) +
     #       the per-pixel state and images (see below; SURVEY 8(d)'s 508 / 548 B per step are the reference's L2-served gathers)
     # (the hit-record stream between the two tri backward kernels is this design's own traffic, not algorithmic)
-    if world > 1 or emu:  # this rank's band
+    if segs is not None:  # this rank's segments
+        R, npix_band = 0, 0
+        for v, rws, sa, _, _ in seg_args[-1:]:  # (the scratch buffers of the last segment's forward are the ones still alive)
+            br = _C.export("ranges", sa, False, o[0], o[-4:], H, W, th.int32).cpu().numpy().reshape(-1, 2).astype(np.int64)
+            R += int((br[:, 1] - br[:, 0]).sum())
+        for v, (r0, r1), _, _, _ in seg_args:
+            npix_band += W * max(0, min(H, r1 * 16) - r0 * 16)
+        if len(seg_args) > 1:  # the roofline's bytes are per launch: the last segment's
+            v, (r0, r1), _, _, _ = seg_args[-1]
+            npix_band = W * max(0, min(H, r1 * 16) - r0 * 16)
+    elif world > 1 or emu:  # this rank's band
         br = _C.export("ranges", args, tet, 0 if tet else o[0], o[-4:], H, W, th.int32).cpu().numpy().reshape(-1, 2).astype(np.int64)
         R = int((br[:, 1] - br[:, 0]).sum())
         npix_band = B * W * max(0, min(H, rows[1] * 16) - rows[0] * 16)
@@ -540,8 +593,12 @@ def main():
                             "host_sync": host_sync,
                             # what the ONE gradient all-reduce of an N-rank run carries: [3P | 3P | F | B*P | B*F] fp32 (tet: [3P | F])
                             "allreduce_payload_bytes": int(flat.numel() * 4),
-                            "parallelism": (f"EMULATED rank {emu[0]} of {emu[1]}: its tile-row band {rows}, no collective" if emu else
-                                            "single GPU" if world == 1 else f"tile-row bands x{world} + 1 RCCL all-reduce")}, **stats),
+                            "parallelism": (f"EMULATED rank {emu[0]} of {emu[1]}: "
+                                            + (f"its (view, row_begin, row_end) segments {segs}" if segs is not None else f"its tile-row band {rows}")
+                                            + ", no collective" if emu else
+                                            "single GPU" if world == 1 else
+                                            f"(view, tile-row band) segments of {B} views x{world} + 1 RCCL all-reduce" if segs is not None
+                                            else f"tile-row bands x{world} + 1 RCCL all-reduce")}, **stats),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stages, "early_out": early,
             "sync": sync_rec, "tet_c3": tet_rec, "tri_c2": others.get("c2"), "tri_c5": others.get("c5"),
         }

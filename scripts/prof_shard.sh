@@ -1,16 +1,18 @@
-# usage: bash scripts/prof_shard.sh <outdir-name> [config] ; rocprofv3 kernel traces of ONE rank's work when the frame (default C4)
+# usage: bash scripts/prof_shard.sh <outdir-name> [config] [partition] ; rocprofv3 kernel traces of ONE rank's work when the frame (default C4)
 # is sharded 1 / 2 / 4 / 8 ways (bench.py --emulate-rank R/N: the rank's tile-row band, one process, no collective): first, middle and
 # last rank of every split -> kernel sums per rank, and the gradient all-reduce's payload
 set -e
 OUT=gpurun_out/$1
 CFG=${2:-C4}
+PART=${3:-auto}
+SPECS=${SPECS:-"0/1 0/2 1/2 0/4 2/4 3/4 0/8 3/8 7/8"}
 STEPS=30; if [ "$CFG" = "C5" ]; then STEPS=8; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for spec in 0/1 0/2 1/2 0/4 2/4 3/4 0/8 3/8 7/8; do
+for spec in $SPECS; do
   tag=$(echo $spec | tr / _)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 bench.py --config $CFG --emulate-rank $spec --steps $STEPS --warmup 3 > $OUT/bench_$tag.json 2> $OUT/trace_$tag.err || true
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 bench.py --config $CFG --emulate-rank $spec --partition $PART --steps $STEPS --warmup 3 > $OUT/bench_$tag.json 2> $OUT/trace_$tag.err || true
   cp $OUT/trace_$tag/*/*_kernel_stats.csv $OUT/kernel_stats_rank_$tag.csv
 done
 python3 - "$OUT" <<'PY'

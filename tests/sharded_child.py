@@ -30,18 +30,28 @@ def run(renderer):
 
 
 full = run(dmr.TriRenderer(settings))
-for assemble in (True, False):
-    sh = sharding.ShardedTriRenderer(settings, assemble=assemble)
-    assert sh.world == world == 2 and sh.rows != (0, 0)
-    c, z, g = run(sh)
-    if assemble:
-        assert th.equal(c, full[0]) and th.equal(z, full[1]), "assembled image differs"
-    else:
-        r0, r1 = sh.rows
-        assert th.equal(c[:, :, 16 * r0:16 * r1], full[0][:, :, 16 * r0:16 * r1]), "band rows differ"
-    for a, b, k in zip(g, full[2], names):
-        e = scenes.rel_err(a.cpu().numpy(), b.cpu().numpy())
-        assert e <= scenes.sum_order_tol(k), (k, e)
+for partition in ("bands", "view_bands"):   # bands of both views per rank / (view, band) segments (B = 2 views, 2 ranks)
+    for assemble in (True, False):
+        sh = sharding.ShardedTriRenderer(settings, assemble=assemble, partition=partition)
+        assert sh.world == world == 2 and sh.rows != (0, 0)
+        if partition == "view_bands":  # the second view costs twice the first: rank 0 renders view 0 and the top of view 1
+            gy = sharding.tile_rows(H)
+            sh.set_row_work(np.stack([np.ones(gy), 2.0 * np.ones(gy)]))
+            sh.segment_cost_per_face = 0.0
+            parts = sh.view_parts(B, t["faces"].shape[0])
+            assert [len(p) for p in parts] == [2, 1], parts
+        c, z, g = run(sh)
+        if assemble:
+            assert th.equal(c, full[0]) and th.equal(z, full[1]), "assembled image differs"
+        elif partition == "bands":
+            r0, r1 = sh.rows
+            assert th.equal(c[:, :, 16 * r0:16 * r1], full[0][:, :, 16 * r0:16 * r1]), "band rows differ"
+        else:
+            for v, r0, r1 in parts[rank]:
+                assert th.equal(c[v, :, 16 * r0:16 * r1], full[0][v, :, 16 * r0:16 * r1]), "this rank's segment differs"
+        for a, b, k in zip(g, full[2], names):
+            e = scenes.rel_err(a.cpu().numpy(), b.cpu().numpy())
+            assert e <= scenes.sum_order_tol(k), (partition, k, e)
 
 # the tet renderer, same sharding (ShardedTetRenderer: bands, one all-gather of the images, ONE all-reduce over [3P | F])
 Ht = Wt = 160

@@ -33,3 +33,15 @@ def test_bench_gpus_2_rehearsal(hip_device):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0
     assert "x2" in j["config"]["parallelism"]
+
+
+def test_bench_emulated_view_band(hip_device):
+    """C5 has B = 4 views: rank 5 of 8 renders its (view, band) segments (sharding.view_shares) with B = 1 tensors."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C5", "--emulate-rank", "5/8", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "segments [(" in j["config"]["parallelism"] and j["value"] > 0

@@ -34,7 +34,7 @@ def _worker(rank, world, port, out_dir):
         d = scenes.layered_sheets(3, 7, B, H, W, seed=1)
         gc, gd = scenes.upstream_grads(B, H, W)
         leaves = {k: d[k].clone().requires_grad_(True) for k in ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")}
-        r = sharding.ShardedTriRenderer(dmr.TriRenderSettings(H, W, d["bg"]), assemble=True, impl=oracle_C)
+        r = sharding.ShardedTriRenderer(dmr.TriRenderSettings(H, W, d["bg"]), assemble=True, impl=oracle_C, partition="bands")
         # work-balanced bands from one full render's per-tile list lengths
         full = oracle_C.render_tris(*scenes.c_args(d), H, W)
         st = oracle_C._state(full[3])[1]
@@ -72,6 +72,81 @@ def test_two_rank_band_sharding(tmp_path, oracle):
             assert np.abs(r["g_" + k] - g.numpy()).max() <= 1e-5 * max(1.0, float(g.abs().max())), k
     for k in ("g_verts", "g_faces_opacity"):
         assert np.array_equal(r0[k], r1[k])
+
+
+def _view_worker(rank, world, port, out_dir):
+    """The "view_bands" partition: B = 2 views on `world` ranks (2: one view per rank; 4: two bands per view; 3: the middle
+    rank's share straddles the view border -- two segments, two B = 1 calls)."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dmesh_renderer_amd as dmr
+        from dmesh_renderer_amd import scenes, sharding
+        import oracle_C
+        H, W, B = 88, 72, 2
+        d = scenes.layered_sheets(3, 7, B, H, W, seed=1)
+        gc, gd = scenes.upstream_grads(B, H, W)
+        full = oracle_C.render_tris(*scenes.c_args(d), H, W)
+        st = oracle_C._state(full[3])[1]
+        gy, gx = sharding.tile_rows(H), (W + 15) // 16
+        res = {}
+        for assemble in (True, False):
+            leaves = {k: d[k].clone().requires_grad_(True) for k in ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")}
+            r = sharding.ShardedTriRenderer(dmr.TriRenderSettings(H, W, d["bg"]), assemble=assemble, impl=oracle_C)  # "auto"
+            r.set_row_work(sharding.view_row_work_from_ranges(st.get("ranges"), B, gy, gx))
+            parts = r.view_parts(B, d["faces"].shape[0])
+            assert r._use_view_bands(B) and len(parts) == world
+            if world == 3:
+                assert [len(p) for p in parts] == [1, 2, 1] and [v for v, _, _ in parts[1]] == [0, 1]
+            else:
+                assert all(len(p) == 1 for p in parts) and [p[0][0] for p in parts] == [k // (world // B) for k in range(world)]
+            covered = np.zeros((B, gy), dtype=np.int64)  # the shares tile the (view, row) sequence exactly once
+            for sh in parts:
+                for v, a, b in sh:
+                    covered[v, a:b] += 1
+            assert (covered == 1).all()
+            color, depth = r(leaves["verts"], d["faces"], leaves["verts_color"], leaves["faces_opacity"],
+                             d["mv_mats"], d["proj_mats"], leaves["verts_depth"], leaves["faces_intense"])
+            ((color * gc).sum() + (depth * gd).sum()).backward()
+            tag = "a" if assemble else "s"
+            res.update({tag + "_color": color.detach().numpy(), tag + "_depth": depth.detach().numpy(),
+                        **{tag + "_g_" + k: v.grad.numpy() for k, v in leaves.items()}})
+        np.savez(os.path.join(out_dir, f"view{rank}.npz"), segs=np.array(parts[rank], dtype=np.int64).reshape(-1, 3), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_view_band_sharding(tmp_path, oracle, world):
+    """with B views, (view, band) segments -- the rows of all views cut into `world` contiguous shares, every
+    segment rendered with B = 1 tensors; one all-gather assembles the images, ONE all-reduce over the all-views flat buffer
+    sums the gradients (a rank's per-view gradients are its views' rows, zero elsewhere).  Every rank ends with the unsharded result."""
+    mp.spawn(_view_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import oracle_C
+    from dmesh_renderer_amd import scenes
+    H, W, B = 88, 72, 2
+    d = scenes.layered_sheets(3, 7, B, H, W, seed=1)
+    gc, gd = scenes.upstream_grads(B, H, W)
+    args = scenes.c_args(d)
+    full = oracle_C.render_tris(*args, H, W)
+    gfull = oracle_C.render_tris_backward(*args, gc, gd, full[0], *full[3:7])
+    names = ("verts", "verts_color", "faces_opacity", "verts_depth", "faces_intense")
+    for rank in range(world):
+        r = np.load(tmp_path / f"view{rank}.npz")
+        assert np.array_equal(r["a_color"], full[1].numpy()) and np.array_equal(r["a_depth"], full[2].numpy())
+        assert len(r["segs"]) >= 1
+        for v, b0, b1 in r["segs"]:  # not assembled: its bands of its views
+            y0, y1 = 16 * int(b0), min(H, 16 * int(b1))
+            assert np.array_equal(r["s_color"][v, :, y0:y1], full[1].numpy()[v, :, y0:y1])
+            assert np.array_equal(r["s_depth"][v][..., y0:y1, :], full[2].numpy()[v][..., y0:y1, :])
+        for tag in ("a", "s"):
+            for k, g in zip(names, gfull):
+                assert np.abs(r[f"{tag}_g_{k}"] - g.numpy()).max() <= 1e-5 * max(1.0, float(g.abs().max())), (tag, k)
 
 
 def _tet_worker(rank, world, port, out_dir):
@@ -163,3 +238,23 @@ def test_band_balance_counts_tiles_as_well_as_list_entries():
     cost = lambda b: lens[:, b[0]:b[1]].sum() + sharding.TILE_COST_ENTRIES * B * gx * (b[1] - b[0])
     spread = lambda bands: max(cost(b) for b in bands) / (sum(cost(b) for b in bands) / world)
     assert spread(by_cost) < spread(by_entries)
+
+
+def test_view_shares_balance_unequal_views():
+    """`view_shares`: contiguous shares of the (view, row) sequence; a share pays `segment_cost` per view it touches; the
+    bisection finds the smallest maximum.  C5-like: views of work 3 : 1.6 : 3 : 1.44 on 8 ranks."""
+    from dmesh_renderer_amd.sharding import view_shares
+    w = np.repeat(np.array([[3.0], [1.6], [3.0], [1.44]]), 64, axis=1)
+    seg = 8.0
+    sh = view_shares(w, 8, seg)
+    assert len(sh) == 8
+    cost = [sum(w[v, a:b].sum() + seg for v, a, b in s) for s in sh]
+    ideal = (w.sum() + 4 * seg) / 8
+    assert max(cost) <= 1.12 * ideal, (cost, ideal)  # equal ranks per view (2 each) would give 3.0 * 32 + 8 = 104 against 72.4
+    covered = np.zeros(w.shape, dtype=np.int64)
+    for s in sh:
+        for v, a, b in s:
+            covered[v, a:b] += 1
+    assert (covered == 1).all()
+    # more ranks than rows: the extra shares are empty
+    assert sum(1 for s in view_shares(np.ones((2, 2)), 6, 0.0) if s) == 4
