@@ -55,11 +55,11 @@ struct ImageState {
     int32_t* first_face; int32_t* first_tet; int32_t* last_face; int32_t* last_tet; uint8_t* is_active;
     float* mats;  // [mv | proj | inv_mv | inv_proj], [B,16] each, contract layout (written by k_project_verts)
     int* seed;    // tet: ray_random_seed of the forward (the backward recomputes the same jittered rays)
-    unsigned long long* mask_offset;  // tri: byte offset of the coverage masks inside the binning buffer (written on the device)
+    unsigned long long* mask_offset;  // tri: {byte offset of the coverage masks inside the binning buffer, their first-chunk slots} (written on the device)
     dmr::TetSeq* seq;  // tet: the march sequence's descriptor (dmr_kernels.hpp)
 };
 struct BinningState {
-    uint64_t* keys; uint32_t* face_list; uint32_t capacity; unsigned long long mask_offset;
+    uint64_t* keys; uint32_t* face_list; uint32_t capacity; unsigned long long mask_offset, mask_first;
     char* base; unsigned long long seq_offset; uint32_t seq_steps;  // tet: the march sequence's region
 };
 
@@ -81,7 +81,7 @@ size_t carve_image(void* b, size_t B, size_t ntiles, size_t npix, bool tet, Imag
     Carver c(b);
     s.mats = c.take<float>(64 * B);
     s.seed = c.take<int>(1);
-    s.mask_offset = c.take<unsigned long long>(1);
+    s.mask_offset = c.take<unsigned long long>(2);
     // counters, zeroed by k_project_verts at the start of a forward: [tile_count | tile_hits | tile_bound | scan_tmp's buckets]
     s.tile_count = c.take<uint32_t>(ntiles); s.tile_hits = c.take<uint32_t>(ntiles); s.tile_bound = c.take<uint32_t>(ntiles);
     s.scan_tmp = c.take<uint32_t>(dmr::scan_tmp_words((int)ntiles));
@@ -113,6 +113,7 @@ size_t carve_binning(void* b, size_t R, size_t mask_tiles, size_t seq_tiles, siz
     s.face_list = c.take<uint32_t>(R); s.keys = c.take<uint64_t>(R);
     s.capacity = (uint32_t)std::min<size_t>(R, 0xffffffffu);
     s.mask_offset = c.off;
+    s.mask_first = dmr::mask_first_slots(R, mask_tiles);
     if (mask_tiles && R > 0) c.take<uint4>(dmr::mask_slots(R, mask_tiles) * 256);
     s.base = reinterpret_cast<char*>(b); s.seq_offset = c.off; s.seq_steps = (uint32_t)seq_steps;
     if (seq_steps) c.take<char>(dmr::tet_seq_bytes(seq_tiles, seq_steps));
@@ -314,7 +315,7 @@ int run_forward(const dmr_scene* s, bool tet, const Dims& d, dmr_alloc_fn alloc,
 
         if (capacity > 0) {
             dmr::launch_scatter_faces(*s, d.gx, d.gy, fs.rect, fs.key_depth, fs.tiles_touched, is.tile_cursor, bs.keys,
-                                      (uint32_t)capacity, tet ? nullptr : is.mask_offset, bs.mask_offset, st);
+                                      (uint32_t)capacity, tet ? nullptr : is.mask_offset, bs.mask_offset, bs.mask_first, st);
             // (up to SCAN_SINGLE_MAX tiles the tri forward / the tet first-hit kernel sort a tile's list at the start of its workgroup)
             if (d.ntiles > dmr::SCAN_SINGLE_MAX)
                 dmr::launch_sort_tiles(d.ntiles, is.tile_offset, is.tile_order, bs.keys, bs.face_list, bs.capacity, st);

@@ -231,9 +231,9 @@ __global__ void __launch_bounds__(256)
 k_scatter_faces_lds(int B, int F, int gx, int gy, const uint2* __restrict__ face_rect,
                     const float* __restrict__ key_depth, const uint32_t* __restrict__ tiles_touched,
                     uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys, uint32_t capacity,
-                    unsigned long long* __restrict__ mask_offset_dst, unsigned long long mask_offset) {
+                    unsigned long long* __restrict__ mask_offset_dst, unsigned long long mask_offset, unsigned long long mask_first) {
     // where the binning buffer of THIS capacity keeps the coverage masks (dmr_kernels.hpp, TriImageState::mask_offset)
-    if (mask_offset_dst && blockIdx.x == 0 && threadIdx.x == 0) *mask_offset_dst = mask_offset;
+    if (mask_offset_dst && blockIdx.x == 0 && threadIdx.x == 0) { mask_offset_dst[0] = mask_offset; mask_offset_dst[1] = mask_first; }
     __shared__ uint32_t s_hist[LDS_HIST_MAX];
     __shared__ int s_box[4];
     __shared__ BigFace s_big[BIG_MAX];
@@ -718,14 +718,14 @@ void launch_scan_hits(int ntiles, const uint32_t* tile_hits, const uint32_t* til
 
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
                           const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
-                          unsigned long long* mask_offset_dst, unsigned long long mask_offset, hipStream_t st) {
+                          unsigned long long* mask_offset_dst, unsigned long long mask_offset, unsigned long long mask_first, hipStream_t st) {
     const int64_t n = (int64_t)s.B * s.F;
     if (n == 0) return;
     StageScope t(DMR_STAGE_SCATTER, st);
     const int fpt = bin_fpt(n);
     const dim3 grid((unsigned)((n + 256 * fpt - 1) / (256 * fpt))), block(256);
 #define DMR_SCATTER(FPT) k_scatter_faces_lds<FPT><<<grid, block, 0, st>>>(s.B, s.F, gx, gy, face_rect, key_depth, tiles_touched, \
-                                                                         tile_cursor, keys, capacity, mask_offset_dst, mask_offset)
+                                                                         tile_cursor, keys, capacity, mask_offset_dst, mask_offset, mask_first)
     if (fpt == 1) DMR_SCATTER(1); else if (fpt == 2) DMR_SCATTER(2); else DMR_SCATTER(4);
 #undef DMR_SCATTER
 }

@@ -71,7 +71,7 @@ void launch_scan_tiles(int ntiles, const uint32_t* tile_count, uint32_t* tile_of
                        uint32_t capacity, uint32_t* overflow, hipStream_t st);
 void launch_scatter_faces(const dmr_scene& s, int gx, int gy, const uint2* face_rect, const float* key_depth,
                           const uint32_t* tiles_touched, uint32_t* tile_cursor, uint64_t* keys, uint32_t capacity,
-                          unsigned long long* mask_offset_dst, unsigned long long mask_offset, hipStream_t st);
+                          unsigned long long* mask_offset_dst, unsigned long long mask_offset, unsigned long long mask_first, hipStream_t st);
 // capacity: entries the binning buffer holds; it is below R only while a size guess is being refuted (dmr_api.hip):
 // every kernel that walks the tile lists clamps to it, the results are then thrown away and redone.
 // (frames above SCAN_SINGLE_MAX tiles: below, the tri forward / the tet first-hit kernel sort their tiles themselves)
@@ -87,12 +87,18 @@ struct TriImageState {
     uint32_t* tile_used;            // records k_tri_backward_pix wrote into a tile's region (padded runs; <= the bound)
     const uint32_t* tile_order;  // all B * gx * gy tiles, longest list first (k_scan_tiles)
     // Coverage masks the forward keeps for the backward: one 4 KB slot (256 pixels x 128 face bits) per 128-entry chunk of a
-    // tile's list, slot = list offset / 128 + tile index.  They live in the binning buffer behind the lists, whose capacity
-    // the backward does not know on the host (speculative sizing): the byte offset is kept on the device.
+    // tile's list.  Chunk 0 of the tile at position q of tile_order (busy tiles come first there: q < number of busy tiles
+    // <= min(tiles, list entries)) is slot q of the first mask_first_slots() slots; chunk c >= 1 of a list that starts at entry
+    // `begin` is slot mask_first_slots() + begin / 128 + c - 1 (the next busy tile's chunks start at or behind
+    // (begin + len) / 128 >= begin / 128 + ceil(len / 128) - 1: no two chunks share a slot).  So the masks grow with the list
+    // entries, not with the tiles of the frame (up to round 2: one slot per tile, empty or not -- 4 GiB for a frame of 1 M
+    // tiles).  They live in the binning buffer behind the lists, whose capacity the backward does not know on the host
+    // (speculative sizing): mask_offset[0] = their byte offset, mask_offset[1] = mask_first_slots(), kept on the device.
     const unsigned long long* mask_offset;
 };
 constexpr int MASK_CHUNK = 128;     // list entries per mask slot = the compositing kernels' chunk
-inline size_t mask_slots(size_t list_capacity, size_t ntiles) { return list_capacity / MASK_CHUNK + ntiles + 1; }
+inline size_t mask_first_slots(size_t list_capacity, size_t ntiles) { return list_capacity < ntiles ? list_capacity : ntiles; }
+inline size_t mask_slots(size_t list_capacity, size_t ntiles) { return mask_first_slots(list_capacity, ntiles) + list_capacity / MASK_CHUNK + 1; }
 // One blended (pixel, face) pair, written face-major per (tile, chunk, pass) by k_tri_backward_pix and
 // consumed one per lane by k_tri_backward_hits.
 // (A 32-byte record carrying face and vertex ids was tried: kernel 2 did not get faster, kernel 1 got 9 % slower.)

@@ -100,12 +100,18 @@ struct TriParams {
     const unsigned long long* mask_offset;  // coverage masks: byte offset behind face_list (TriImageState)
 };
 
-// The chunk's coverage masks, pixel-major: slot (list offset / 128 + tile + chunk) of 256 x 16 bytes.  The forward writes
-// them right after rasterising, the per-pixel backward reads them back instead of staging the coverage records and
+// The tile's coverage masks, pixel-major, one slot of 256 x 16 bytes per chunk (layout: TriImageState, dmr_kernels.hpp): chunk
+// 0 in the slot of the tile's position in tile_order, the later chunks behind the list offset.  The forward writes them
+// right after rasterising, the per-pixel backward reads them back instead of staging the coverage records and
 // rasterising the chunk a second time (that was 13 k of its 25 k cycles per chunk, profiles/r02/phase_times_c4.txt).
-__device__ __forceinline__ uint4* chunk_masks(const TriParams& p, int tile, uint32_t begin, uint32_t chunk) {
-    char* base = const_cast<char*>(reinterpret_cast<const char*>(p.face_list)) + *p.mask_offset;
-    return reinterpret_cast<uint4*>(base) + ((size_t)(begin / (uint32_t)MASK_CHUNK) + (size_t)tile + chunk) * TILE_PIX;
+struct ChunkMasks {
+    uint4* first; uint4* rest;
+    __device__ __forceinline__ uint4* at(uint32_t chunk) const { return chunk == 0u ? first : rest + (size_t)chunk * TILE_PIX; }
+};
+__device__ __forceinline__ ChunkMasks chunk_masks(const TriParams& p, uint32_t order_pos, uint32_t begin) {
+    uint4* base = reinterpret_cast<uint4*>(const_cast<char*>(reinterpret_cast<const char*>(p.face_list)) + p.mask_offset[0]);
+    // (chunk c >= 1: slot first_slots + begin / 128 + c - 1; first_slots >= 1 whenever a list has an entry)
+    return {base + (size_t)order_pos * TILE_PIX, base + ((size_t)p.mask_offset[1] + (size_t)(begin / (uint32_t)MASK_CHUNK) - 1u) * TILE_PIX};
 }
 
 // Staging a list entry is a chain of dependent gathers: face_list -> faces (+ opacity, intensity) -> 3 x
@@ -260,6 +266,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
     __shared__ uint32_t s_hits[4];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long mask_first_slots = p.mask_offset[1];  // (requested with the tile's id, not behind its list range)
     // tiles are taken longest list first (tile_order, k_scan_tiles); rows outside this shard's band are skipped
     const int tile = (int)p.tile_order[blockIdx.x];
     const int tx = tile % p.gx, ty = (tile / p.gx) % p.gy, b = tile / (p.gx * p.gy);
@@ -272,8 +279,10 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 
     // A list that does not fit the binning buffer (only while a size guess is being refuted; everything is redone
     // then) was neither completely scattered nor sorted: its entries are not face ids.  Such a tile renders as empty.
+    // (The same for a tile whose position in tile_order has no first-chunk mask slot: more busy tiles than list capacity.)
     uint32_t begin = p.tile_offset[tile], end = p.tile_offset[tile + 1];
     if (end > p.list_capacity) begin = end = 0u;
+    if ((unsigned long long)blockIdx.x >= mask_first_slots) begin = end = 0u;
     if (begin == end) {  // an empty tile (most of a frame: 5 244 of C4's 8 160) is background: no rays, no LDS, no barriers
         if (inside) {
             const int64_t bpix = (int64_t)b * HW + pix_id;
@@ -307,7 +316,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 
     DMR_STAMP_RT(p, 0, 0);
     static_assert(CHUNK == MASK_CHUNK, "one mask slot per chunk");
-    uint4* __restrict__ masks = chunk_masks(p, tile, begin, 0u);
+    const ChunkMasks masks = chunk_masks(p, blockIdx.x, begin);
     AllDone all_done;
     all_done.init(s_live);
     for (uint32_t base = begin; base < end; base += CHUNK) {
@@ -331,7 +340,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         {
             const uint4 mm = *reinterpret_cast<const uint4*>(&s_pm[ly * TILE + lx][0]);
             m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
-            masks[(size_t)ph * TILE_PIX + (ly * TILE + lx)] = mm;  // kept for the backward (every pixel: it applies its own bound)
+            masks.at(ph)[ly * TILE + lx] = mm;  // kept for the backward (every pixel: it applies its own bound)
         }
 #pragma unroll
         for (int w = 0; w < WORDS; w++) if (done || DMR_DBG(p, 8)) m[w] = 0;
@@ -643,7 +652,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         const uint32_t lo = (nchunks - 1u - ci) * CHUNK, hi = min(total, lo + (uint32_t)CHUNK);
         return lo + (uint32_t)sj < hi ? (int)p.face_list[begin + lo + sj] : -1;
     };
-    const uint4* __restrict__ masks = chunk_masks(p, tile, begin, 0u);
+    const ChunkMasks masks = chunk_masks(p, blockIdx.x, begin);
     FaceIds ids = load_face_ids(p, b, chunk_face(0));
     int face_next = chunk_face(1);
     DMR_STAMP_RT(p, 1, 0);
@@ -654,7 +663,7 @@ k_tri_backward_pix(TriParams p, const float* __restrict__ dL_dcolor, const float
         DMR_STAMP(p, 1, ci, 0);
         // ---- A: this pixel's coverage bits of the chunk, as the forward's rasterisation left them (requested before the
         // barrier, in flight across it), restricted to list positions below the pixel's n_contrib (backward.cu:192-194)
-        uint4 mm = masks[(size_t)fc * TILE_PIX + pl];
+        uint4 mm = masks.at(fc)[pl];
         __syncthreads();  // previous chunk is done with the LDS records and cursors
         DMR_STAMP(p, 1, ci, 1);
         if (tid < CHUNK) {

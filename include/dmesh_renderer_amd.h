@@ -44,8 +44,9 @@ enum { DMR_BUF_POINT = 0, DMR_BUF_FACE = 1, DMR_BUF_BINNING = 2, DMR_BUF_IMAGE =
 /* Footprints (bytes; B views, P verts, F faces, T tets, Nt = B * ceil(W/16) * ceil(H/16) tiles, R list entries; every
  * sub-array rounded up to 256): point 16 BP; face 16 BF (tet: 20 BF + 128 F + 224 T); image ~76 B + 40 Nt + 12 BWH (tet: 29 BWH);
  * binning 12 R', R' = R or, with a size estimate, 1.25 R_prev + 4096 -- plus, tri only, the coverage masks the forward
- * leaves for the backward: 4096 (R'/128 + Nt + 1), i.e. 32 B per list entry AND 4 KB PER TILE, busy or not (the reference's
- * binning buffer scales with R only: a 1 M-tile frame costs 4 GiB here) -- plus, tet only, the forward's march sequence for
+ * leaves for the backward: 4096 (R'/128 + min(Nt, R') + 1), i.e. 32 B per list entry and 4 KB per tile that can be busy (a
+ * tile's first chunk has the slot of the tile's rank among the busy tiles, so a sparse frame of 1 M tiles pays for its list
+ * entries, not 4 GiB for its tiles; the reference's binning buffer scales with R only) -- plus, tet only, the forward's march sequence for
  * the backward: 4 bytes per tile pixel (256 Nt of them) and step of capacity, capacity = the longest march of the previous
  * call with the same view configuration * 1.25 + 4 steps (0 in the first such call), the whole capped at 16 GiB;
  * work (tri backward) 32 BP + 8 BF + 8192 Nt + 16 per hit record. */

@@ -40,6 +40,9 @@ CASES = {
     # (Q7) for tiles far from the vertices, so the per-tile pixel box may only be trusted near them (edge_setup's
     # 2^14 bound); every one of the 65 536 tiles holds a short list
     "span_4000": (2, 2, 1, 4096, 4096, (0.1, 0.4)),
+    # a small mesh in the middle of a 2048^2 frame: 16 384 tiles, far fewer list entries than tiles -- the coverage masks'
+    # first-chunk slots are numbered by the tile's rank among the busy tiles and there are only min(tiles, entries) of them
+    "sparse_tiles": (3, 8, 1, 2048, 2048, (0.1, 0.5)),
 }
 
 
@@ -50,6 +53,8 @@ def _make(case):
         d["verts"] = d["verts"] * th.tensor([40.0, 40.0, 3.0])
     if case == "span_4000":
         d["verts"] = d["verts"] * th.tensor([1.7, 1.7, 1.0])
+    if case == "sparse_tiles":
+        d["verts"] = d["verts"] * th.tensor([0.2, 0.2, 1.0])
     if case == "many_big":
         d["verts"] = d["verts"] * th.tensor([6.0, 6.0, 1.0])
     if case == "alpha_one":
