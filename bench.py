@@ -338,6 +338,23 @@ def main():
     # (behind the early-out scene's different buffer sizes the same steps measure 1-5 % slower: where the caching allocator
     # places the work buffer) -- what a user of the drop-in TriRenderer / `_C` gets without opting into asynchronous calls.
     ms_main, cnt_main = collect()
+    # N > 1: the all-reduced gradients of the last timed step against ONE rank rendering the whole frame alone (untimed; every
+    # rank does it -- the collective above needs no partner here): what the sharding and the collective must not change
+    sharded_err = None
+    if world > 1:
+        summed = flat.clone()
+        fo = forward()
+        full = th.empty_like(flat)
+        if tet:
+            _C.render_tets_backward(*args, gc, gd, *fo[-4:], flat_out=full)
+        else:
+            _C.render_tris_backward(*args, gc, gd, fo[0], *fo[-4:], flat_out=full)
+        sizes = (3 * P, F) if tet else (3 * P, 3 * P, F, B * P, B * F)
+        sharded_err, at = 0.0, 0
+        for n in sizes:
+            sharded_err = max(sharded_err, rel_err(summed[at:at + n].cpu().numpy(), full[at:at + n].cpu().numpy()))
+            at += n
+        del summed, full, fo
     sync_rec = None
     if world == 1 and not emu and rank == 0 and not a.sync and not a.opacity and not overflowed:
         for _ in range(max(3, a.warmup)):  # a few default steps first: the timed ones before were asynchronous
@@ -600,6 +617,7 @@ def main():
                                             f"(view, tile-row band) segments of {B} views x{world} + 1 RCCL all-reduce" if segs is not None
                                             else f"tile-row bands x{world} + 1 RCCL all-reduce")}, **stats),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "stages_ms": stages, "early_out": early,
+            "sharded_grad_max_norm_err": sharded_err,  # N > 1: all-reduced gradients vs one rank's whole-frame gradients
             "sync": sync_rec, "tet_c3": tet_rec, "tri_c2": others.get("c2"), "tri_c5": others.get("c5"),
         }
         if tet:

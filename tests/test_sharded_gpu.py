@@ -33,6 +33,7 @@ def test_bench_gpus_2_rehearsal(hip_device):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0
     assert "x2" in j["config"]["parallelism"]
+    assert j["sharded_grad_max_norm_err"] is not None and j["sharded_grad_max_norm_err"] <= 5e-5
 
 
 def test_bench_emulated_view_band(hip_device):
@@ -45,3 +46,20 @@ def test_bench_emulated_view_band(hip_device):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert "segments [(" in j["config"]["parallelism"] and j["value"] > 0
+
+
+def test_bench_gpus_2_view_segments(hip_device):
+    """`bench.py --gpus 2 --config C5`: two ranks (gloo, one GPU) step their (view, band) segments of the four views with
+    B = 1 tensors and join ONE all-reduce over the all-views payload."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DMR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C5", "--steps", "2",
+                        "--warmup", "1", "--settle-ms", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    assert "segments of 4 views x2" in j["config"]["parallelism"]
+    assert j["config"]["allreduce_payload_bytes"] == 80320640
+    assert j["sharded_grad_max_norm_err"] is not None and j["sharded_grad_max_norm_err"] <= 5e-5
