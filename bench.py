@@ -152,7 +152,7 @@ def main():
 
     from dmesh_renderer_amd import _C, scenes
     from dmesh_renderer_amd.scenes import c_args, max_abs_err, rel_err, upstream_grads
-    from dmesh_renderer_amd.sharding import (SEGMENT_COST_PER_FACE, balanced_bands, row_work_from_ranges, view_row_work_from_ranges,
+    from dmesh_renderer_amd.sharding import (balanced_bands, row_work_from_ranges, segment_cost, view_row_work_from_ranges,
                                              view_shares)
 
     cfg = scenes.CONFIGS[a.config]
@@ -189,7 +189,8 @@ def main():
     if tet:  # S = marched (pixel, face) pairs
         stats["marched_pairs"] = int(_C.export("n_contrib", args, True, 0, bufs, H, W, th.int32).sum().item())
     else:    # blended (pixel, face) pairs: what the backward's record stream holds
-        stats["blended_pairs"] = int(_C.export("tile_hits", args, False, out[0], bufs, H, W, th.int32).long().sum().item())
+        tile_hits = _C.export("tile_hits", args, False, out[0], bufs, H, W, th.int32).cpu().numpy().astype(np.int64)
+        stats["blended_pairs"] = int(tile_hits.sum())
     rows = (0, 0)
     emu = None
     if a.emulate_rank:
@@ -200,7 +201,7 @@ def main():
     # of equal cost; a rank renders its segments with B = 1 tensors -- it projects, bins and scatters ONE view's faces per call
     segs = None
     if (world > 1 or emu) and not tet and B > 1 and a.partition != "bands":
-        segs = view_shares(view_row_work_from_ranges(ranges, B, gy, gx), nparts, SEGMENT_COST_PER_FACE * F)[part]
+        segs = view_shares(view_row_work_from_ranges(ranges, B, gy, gx, tile_hits=tile_hits), nparts, segment_cost(F, True))[part]
         segs = segs or [(0, gy, gy)]  # a rank without rows still steps (and joins the collective): an empty band
     elif a.partition == "view_bands" and (world > 1 or emu):
         raise SystemExit("--partition view_bands needs a tri config with B > 1")
@@ -212,7 +213,7 @@ def main():
                 sa[i] = args[i][v:v + 1].contiguous()
             seg_args.append((v, (r0, r1), sa, gc[v:v + 1].contiguous(), gd[v:v + 1].contiguous()))
     elif world > 1 or emu:
-        rows = balanced_bands(row_work_from_ranges(ranges, B, gy, gx), nparts)[part]
+        rows = balanced_bands(row_work_from_ranges(ranges, B, gy, gx, tile_hits=None if tet else tile_hits), nparts)[part]
         if rows[1] <= rows[0]:
             rows = (gy, gy)  # an empty band ((0, 0) would mean "all rows")
     del out, bufs

@@ -69,29 +69,46 @@ def balanced_bands(row_work: Sequence[float], world: int) -> List[Tuple[int, int
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
-# What a tile costs besides its list entries, in list entries (its workgroups in the three tile kernels, its pixels' state and
-# images, its share of the scans).  From the per-rank kernel sums of C5 cut eight ways by list entries alone
-# (profiles/r03/shard_kernel_sums_c5.json, first cut: the edge bands, 72 tile rows, took 2.14 ms, the middle band, 19 rows with
-# the same number of entries, 1.64 ms): 0.5 ms per 54 000 tiles against 1.64 ms per 2.34 M entries.
-TILE_COST_ENTRIES = 13.0
-
-
-def row_work_from_ranges(ranges: np.ndarray, B: int, gy: int, gx: int, tile_cost: float = TILE_COST_ENTRIES) -> np.ndarray:
-    """Per-tile-row work from the per-tile [start, end) list ranges of one full forward: list entries + a cost per tile."""
-    r = np.asarray(ranges).reshape(B, gy, gx, 2).astype(np.int64)
-    return (r[..., 1] - r[..., 0]).sum(axis=(0, 2)) + tile_cost * B * gx
-
-
-def view_row_work_from_ranges(ranges: np.ndarray, B: int, gy: int, gx: int, tile_cost: float = TILE_COST_ENTRIES) -> np.ndarray:
-    """[B, rows]: the same per view (for the "view_bands" partition, `ShardedTriRenderer.set_row_work`)."""
-    r = np.asarray(ranges).reshape(B, gy, gx, 2).astype(np.int64)
-    return (r[..., 1] - r[..., 0]).sum(axis=2) + tile_cost * gx
-
-
+# The cost model the partitions balance, in list entries.  Fitted on 21 measured shares of C5 (ms per step of one rank's work when
+# the frame is cut 1 / 2 / 4 / 8 ways as bands of all views and 4 / 8 ways as (view, band) segments,
+# profiles/r03/shard_cost_model_c5.txt): ms = 1.58e-7 entries + 1.31e-8 blended pairs + 6.97e-6 tiles + 0.19 per view a call bins
+# (rms error 6 %, largest 11 %).  Without the pairs (only the list ranges are known): 3.76e-7 entries + 2.45e-6 tiles + 0.21 per
+# view (rms 11 %, largest 19 %) -- the constants of round 3's first cut, 13 entries per tile, came from three of those shares.
+TILE_COST_ENTRIES = 13.0          # ... per tile of the rows, busy or not, when only list lengths are known
+PAIR_COST_ENTRIES = 0.083         # ... per blended (pixel, face) pair (`tile_hits` of a forward), and then
+TILE_COST_ENTRIES_WITH_PAIRS = 44.0
 # What one (view, band) call costs before any tile is composited -- projecting the vertices, setting up, scanning and scattering
-# the view's faces, unpacking the gradients -- in list entries per face.  C5 (profiles/r03/shard_kernel_sums_c5*.json): 118 us per
-# call for 2 M faces where the tile kernels take 0.36 ns per list entry (+ TILE_COST_ENTRIES per tile).
-SEGMENT_COST_PER_FACE = 0.16
+# the view's faces, unpacking the gradients -- in list entries per face (C5: 2 M faces, 0.19-0.21 ms per view and call).
+SEGMENT_COST_PER_FACE = 0.27
+SEGMENT_COST_PER_FACE_WITH_PAIRS = 0.7
+
+
+def _row_entries(ranges, B: int, gy: int, gx: int) -> np.ndarray:
+    r = np.asarray(ranges).reshape(B, gy, gx, 2).astype(np.int64)
+    return (r[..., 1] - r[..., 0]).sum(axis=2).astype(np.float64)  # [B, rows]
+
+
+def view_row_work_from_ranges(ranges: np.ndarray, B: int, gy: int, gx: int, tile_cost: Optional[float] = None,
+                              tile_hits: Optional[np.ndarray] = None) -> np.ndarray:
+    """[B, rows] work per view and tile row from the per-tile [start, end) list ranges of one full forward (and, better, its
+    per-tile blended-pair counts `tile_hits`, `_C.export("tile_hits", ...)`): the cost model above, in list entries.  For the
+    "view_bands" partition (`ShardedTriRenderer.set_row_work`, `view_shares`)."""
+    w = _row_entries(ranges, B, gy, gx)
+    if tile_hits is None:
+        return w + (TILE_COST_ENTRIES if tile_cost is None else tile_cost) * gx
+    pairs = np.asarray(tile_hits).reshape(B, gy, gx).astype(np.int64).sum(axis=2)
+    return w + PAIR_COST_ENTRIES * pairs + (TILE_COST_ENTRIES_WITH_PAIRS if tile_cost is None else tile_cost) * gx
+
+
+def row_work_from_ranges(ranges: np.ndarray, B: int, gy: int, gx: int, tile_cost: Optional[float] = None,
+                         tile_hits: Optional[np.ndarray] = None) -> np.ndarray:
+    """Per-tile-row work summed over the views (the "bands" partition: `balanced_bands`, `set_row_work`)."""
+    return view_row_work_from_ranges(ranges, B, gy, gx, tile_cost, tile_hits).sum(axis=0)
+
+
+def segment_cost(F: int, with_pairs: bool) -> float:
+    """What a (view, band) call costs besides its rows, in the units of view_row_work_from_ranges."""
+    return (SEGMENT_COST_PER_FACE_WITH_PAIRS if with_pairs else SEGMENT_COST_PER_FACE) * F
 
 
 def view_shares(view_row_work, world: int, segment_cost: float = 0.0) -> List[List[Tuple[int, int, int]]]:
@@ -346,13 +363,15 @@ class ShardedTriRenderer(th.nn.Module):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bands = equal_bands(tile_rows(render_settings.image_height), self.world)
         self.view_work = None   # "view_bands": [B, rows] work of the (view, tile row) sequence; None: every row counts the same
-        self.segment_cost_per_face = SEGMENT_COST_PER_FACE
+        self.segment_cost_per_face = SEGMENT_COST_PER_FACE  # (SEGMENT_COST_PER_FACE_WITH_PAIRS when the row work counts blended pairs)
         self._parts_key, self._parts = None, None
 
-    def set_row_work(self, row_work) -> None:
+    def set_row_work(self, row_work, with_pairs: bool = False) -> None:
         """row_work: per tile row (summed over the views; `row_work_from_ranges`) or per view and tile row ([B, rows];
-        `view_row_work_from_ranges`) -- the latter also balances the shares of the "view_bands" partition."""
+        `view_row_work_from_ranges`) -- the latter also balances the shares of the "view_bands" partition.  with_pairs: the
+        work was computed with `tile_hits` (the blended pairs are in it): a (view, band) call's fixed cost is in those units."""
         w = np.asarray(row_work, dtype=np.float64)
+        self.segment_cost_per_face = SEGMENT_COST_PER_FACE_WITH_PAIRS if with_pairs else SEGMENT_COST_PER_FACE
         if w.ndim == 2:
             self.view_work, self._parts_key = w.copy(), None
             w = w.sum(axis=0)

@@ -258,3 +258,26 @@ def test_view_shares_balance_unequal_views():
     assert (covered == 1).all()
     # more ranks than rows: the extra shares are empty
     assert sum(1 for s in view_shares(np.ones((2, 2)), 6, 0.0) if s) == 4
+
+
+def test_row_work_counts_blended_pairs_when_given():
+    """With `tile_hits` (blended pairs per tile of a forward) the work of a row is entries + PAIR_COST_ENTRIES per pair +
+    TILE_COST_ENTRIES_WITH_PAIRS per tile (the model fitted in profiles/r03/shard_cost_model_c5.txt): two rows with the same
+    list entries but different coverage no longer weigh the same."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from dmesh_renderer_amd import sharding
+    B, gy, gx = 1, 4, 8
+    lens = np.full((B, gy, gx), 100, dtype=np.int64)
+    ends = np.cumsum(lens.reshape(-1))
+    ranges = np.stack([ends - lens.reshape(-1), ends], axis=1)
+    hits = np.zeros((B, gy, gx), dtype=np.int64)
+    hits[0, 0] = 20000  # the first row's faces cover many pixels
+    w0 = sharding.view_row_work_from_ranges(ranges, B, gy, gx)
+    w1 = sharding.view_row_work_from_ranges(ranges, B, gy, gx, tile_hits=hits)
+    assert w0.shape == w1.shape == (B, gy) and np.allclose(w0[0], w0[0, 0])
+    assert np.isclose(w1[0, 1], 100 * gx + sharding.TILE_COST_ENTRIES_WITH_PAIRS * gx)
+    assert np.isclose(w1[0, 0] - w1[0, 1], sharding.PAIR_COST_ENTRIES * 20000 * gx)
+    assert np.allclose(sharding.row_work_from_ranges(ranges, B, gy, gx, tile_hits=hits), w1.sum(axis=0))
+    assert sharding.segment_cost(1000, True) > sharding.segment_cost(1000, False) > 0
