@@ -441,8 +441,17 @@ def main():
                     "frac": round(insts * cpi / 1024 / 2.4e9 / (dom_ms * 1e-3), 4),
                     # active lanes per issued VALU instruction: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), one counter pass
                     "lane_util": round(float(pj["valu_lane_util"]), 4) if pj.get("valu_lane_util") else None, "source": src}
-    note = ("neither HBM- nor VALU-bound: a tile is a serial chain of barrier-separated phases (~6 us per 128-face chunk even on an idle "
-            "chip) and the CU holds 3-6 such chains; SQ_WAIT_ANY ~50 %, VALU issue ~40 % of its 2.25-cycle peak (DESIGN.md section 4)")
+            # ... and how busy the VALUs were by the counters' own account: rocprof's VALUBusy with the kernel's busy CU-cycles as the
+            # time base, SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES (one counter pass, scripts/prof_valu_mix.sh).  "frac" above prices every
+            # instruction at the 2.25 cycles of a plain fp32 add / mul; most of these kernels' instructions are of the 4.5-cycle
+            # kind (compares, selects, integer multiply-adds, fma with a register-bank conflict: profiles/r03/valu_classes.txt).
+            mj, msrc = committed("valu_mix")
+            if mj and mj.get("SQ_ACTIVE_INST_VALU") and mj.get("SQ_BUSY_CU_CYCLES"):
+                valu["busy"] = round(float(mj["SQ_ACTIVE_INST_VALU"]) / float(mj["SQ_BUSY_CU_CYCLES"]), 4)
+                valu["busy_source"] = msrc
+    note = ("HBM is not the bound: the compositing kernels are VALU-bound -- SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES = 0.97 (forward), "
+            "0.75 (per-pixel backward), 0.74 (hit-parallel backward) at C4 -- with most instructions of the 4.5-cycle kind (integer, "
+            "compare, select), and a tile's serial chain of barrier-separated phases on top (DESIGN.md section 4)")
     if tet:
         note = ("algorithmic bytes = this design's compulsory HBM traffic (packed mesh records once, 4 B per marched pair of the march "
                 "sequence, per-pixel state and images); the per-step record gathers are served by L2 (the mesh is 6.5 MB) and are not "

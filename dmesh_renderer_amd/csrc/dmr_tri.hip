@@ -237,8 +237,11 @@ __device__ __forceinline__ void rasterize_faces(const CovRec* __restrict__ cov, 
     }
 }
 
+// (launch_bounds(256, 6) instead of (256, 4): the same six waves per SIMD -- the kernel needed 77 registers either way -- but a
+// register allocation and schedule made for them: k_tri_forward 84.7 -> 79.1 us at C4 on the same box,
+// profiles/r03/variants_launch_bounds_c4.txt; (256, 7) = 72 registers: 86.9)
 #ifndef DMR_FWD_WAVES
-#define DMR_FWD_WAVES 4
+#define DMR_FWD_WAVES 6
 #endif
 #ifndef DMR_PIX_WAVES
 #define DMR_PIX_WAVES 6
@@ -345,6 +348,9 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
 #pragma unroll
         for (int w = 0; w < WORDS; w++) if (done || DMR_DBG(p, 8)) m[w] = 0;
         if (__all(done)) continue;  // wave-uniform
+        // (Unpacking a pixel's bits into a byte list of face numbers in its own 16-byte row of s_pm first, so that the walk reads a
+        // byte per pair instead of picking "the lowest set bit of four words" -- ~22 instructions of the 4.5-cycle kind -- was
+        // measured: 84.2 us against 79.1 for this loop on the same box, profiles/r03/dead_ends.md.)
         while (true) {
             int w = -1; uint32_t mw = 0;
 #pragma unroll
