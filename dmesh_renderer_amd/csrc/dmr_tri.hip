@@ -298,7 +298,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         return;  // uniform
     }
 
-    if (SORT) {
+    if (SORT && !DMR_DBG(p, 262144)) {  // (ablation build, bit 262144: unsorted lists -- timing and instruction counts only)
         sort_tile(begin, end - begin, reinterpret_cast<uint64_t*>(p.keys), const_cast<uint32_t*>(p.face_list),
                   reinterpret_cast<uint64_t*>(s_mem), reinterpret_cast<uint32_t*>(s_mem + SORT_LDS_KEYS * sizeof(uint64_t)), (uint32_t)tid);
         __syncthreads();  // face_list[begin, end) is sorted and visible to this workgroup; the LDS is free
