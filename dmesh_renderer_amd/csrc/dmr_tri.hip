@@ -237,9 +237,9 @@ __device__ __forceinline__ void rasterize_faces(const CovRec* __restrict__ cov, 
     }
 }
 
-// (launch_bounds(256, 6) instead of (256, 4): the same six waves per SIMD -- the kernel needed 77 registers either way -- but a
-// register allocation and schedule made for them: k_tri_forward 84.7 -> 79.1 us at C4 on the same box,
-// profiles/r03/variants_launch_bounds_c4.txt; (256, 7) = 72 registers: 86.9)
+// (launch_bounds(256, 6): six waves per SIMD is what the kernel's 77 registers and 24.6 KB of LDS give; (256, 4) compiles to the
+// same speed -- 76.5-77.3 against 76.9-77.7 us at C4 on one box, profiles/r03/variants_launch_bounds_c4.txt --, (256, 7) = 72
+// registers: 86.9)
 #ifndef DMR_FWD_WAVES
 #define DMR_FWD_WAVES 6
 #endif
@@ -350,7 +350,7 @@ k_tri_forward(TriParams p, float* __restrict__ out_color, float* __restrict__ ou
         if (__all(done)) continue;  // wave-uniform
         // (Unpacking a pixel's bits into a byte list of face numbers in its own 16-byte row of s_pm first, so that the walk reads a
         // byte per pair instead of picking "the lowest set bit of four words" -- ~22 instructions of the 4.5-cycle kind -- was
-        // measured: 84.2 us against 79.1 for this loop on the same box, profiles/r03/dead_ends.md.)
+        // measured: 84 us against 77-79 for this loop, profiles/r03/dead_ends.md.)
         while (true) {
             int w = -1; uint32_t mw = 0;
 #pragma unroll
