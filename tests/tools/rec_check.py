@@ -1,4 +1,5 @@
-"""The forward-record path (second and later calls of a view configuration) against the round-2 path (first call) and the
+"""(Belongs to profiles/r03/fused_records_experiment.patch; on this tree all three calls take the same path.)  The forward-record
+path (second and later calls of a view configuration) against the round-2 path (first call) and the
 oracle, with the per-stage times of both.   python tests/tools/rec_check.py [C1 C2 C4 early ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
