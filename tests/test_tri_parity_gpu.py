@@ -340,3 +340,30 @@ def test_empty_band_renders_nothing(oracle, hip_device):
         th.cuda.synchronize()
         for t in g:
             assert float(t.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("copies,layers", [(40, 3), (150, 2), (700, 1), (20, 8)])
+def test_sort_with_equal_and_bunched_depths(oracle, hip_device, copies, layers):
+    """The tile sort's bucket path (dmr_sort.hpp): every face of a small layered scene duplicated `copies` times -- the copies
+    have bit-identical depth keys and sort by face id -- so a tile's list is `layers` bunches of equal keys: bunches that fit a
+    bucket are ranked inside it (40, 20 copies), larger ones send the tile to the segmented rank sort (150), lists beyond 2 048
+    entries to the bitonic network (700).  face_list must be the reference's stable (depth, emission order) order bit for bit."""
+    from dmesh_renderer_amd import _C
+    B, H, W = 1, 48, 64
+    d = scenes.layered_sheets(layers, 3, B, H, W, seed=7, opacity=(0.002, 0.01))
+    F0 = d["faces"].shape[0]
+    d["faces"] = d["faces"].repeat(copies, 1).contiguous()
+    d["faces_opacity"] = d["faces_opacity"].repeat(copies).contiguous()
+    d["faces_intense"] = d["faces_intense"].repeat(1, copies).contiguous()
+    assert d["faces"].shape[0] == F0 * copies
+    sc, (ocolor, odepth, ost), args, out = _run(oracle, hip_device, d, H, W)
+    R, bufs = out[0], out[3:7]
+    assert R == ost.num_rendered
+    ex = lambda name, dtype: _C.export(name, args, False, R, bufs, H, W, dtype).cpu().numpy()
+    ranges = ost.get("ranges").reshape(-1, 2)
+    longest = int((ranges[:, 1].astype(np.int64) - ranges[:, 0].astype(np.int64)).max())
+    assert longest > 64 and (copies != 700 or longest > 2048), longest  # the lists this test is about
+    np.testing.assert_array_equal(ex("ranges", th.int32).view(np.uint32), ost.get("ranges"))
+    np.testing.assert_array_equal(ex("face_list", th.int32).view(np.uint32), ost.get("values"))
+    np.testing.assert_array_equal(ex("n_contrib", th.int32).view(np.uint32), ost.get("n_contrib"))
+    assert np.abs(out[1].cpu().numpy() - ocolor).max() <= FWD_TOL
