@@ -449,8 +449,8 @@ def main():
             if mj and mj.get("SQ_ACTIVE_INST_VALU") and mj.get("SQ_BUSY_CU_CYCLES"):
                 valu["busy"] = round(float(mj["SQ_ACTIVE_INST_VALU"]) / float(mj["SQ_BUSY_CU_CYCLES"]), 4)
                 valu["busy_source"] = msrc
-    note = ("HBM is not the bound: the compositing kernels are VALU-bound -- SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES = 0.97 (forward), "
-            "0.75 (per-pixel backward), 0.74 (hit-parallel backward) at C4 -- with most instructions of the 4.5-cycle kind (integer, "
+    note = ("HBM is not the bound: the compositing kernels are VALU-bound -- SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES = 0.93 (forward), "
+            "0.76 (per-pixel backward), 0.74 (hit-parallel backward) at C4 -- with most instructions of the 4.5-cycle kind (integer, "
             "compare, select), and a tile's serial chain of barrier-separated phases on top (DESIGN.md section 4)")
     if tet:
         note = ("algorithmic bytes = this design's compulsory HBM traffic (packed mesh records once, 4 B per marched pair of the march "
