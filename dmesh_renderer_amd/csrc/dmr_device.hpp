@@ -191,6 +191,20 @@ __device__ __forceinline__ bool ray_tri_hit(V3 o, V3 d, V3 p0, V3 p1, V3 p2, V3&
     return (tuv.x >= 0.0f && tuv.y >= 0.0f && tuv.z >= 0.0f && tuv.y + tuv.z <= 1.0f);
 }
 
+// ... with the two edge vectors E1 = p1 - p0, E2 = p2 - p0 given (the tet march's records keep them: the same subtractions,
+// done once per tet and face instead of once per ray and step)
+__device__ __forceinline__ bool ray_tri_hit_edges(V3 o, V3 d, V3 p0, V3 E1, V3 E2, V3& tuv) {
+    V3 T = o - p0;
+    V3 P = cross(d, E2), Q = cross(T, E1);
+    float denom = dot(P, E1);
+    if (denom == 0.0f) return false;
+    float inv_denom = 1.0f / denom;
+    tuv.x = dot(Q, E2) * inv_denom;
+    tuv.y = dot(P, T) * inv_denom;
+    tuv.z = dot(Q, d) * inv_denom;
+    return (tuv.x >= 0.0f && tuv.y >= 0.0f && tuv.z >= 0.0f && tuv.y + tuv.z <= 1.0f);
+}
+
 __device__ __forceinline__ V3 load_v3(const float* __restrict__ a, int id) {
     return {a[3 * id], a[3 * id + 1], a[3 * id + 2]};
 }

@@ -32,7 +32,7 @@ static_assert(sizeof(TetColRec) == 64, "TetColRec");
 
 // Per tet: everything a march step needs of it, in ONE 224-byte record -- its four faces (id | slot of the face in the tet
 // behind it << 29 | orientation flip << 31), the tets behind them (-1: none) and, per face, the three vertices and the unit
-// normal before orientation.  A step used to be tet record -> three face records: two dependent levels of gathers; the march
+// normal before orientation (round 3: the vertex p0 and the edge vectors p1 - p0, p2 - p0).  A step used to be tet record -> three face records: two dependent levels of gathers; the march
 // now carries the slot its current face has in its current tet, so the step's eleven loads go out together, one level.
 struct alignas(16) TetBlock { int face[4]; int nbr[4]; float geo[4][12]; };
 static_assert(sizeof(TetBlock) == 224, "TetBlock");
@@ -131,8 +131,19 @@ k_tet_prep_tets(int T, int F, const float* __restrict__ verts, const int* __rest
         }
         r.face[i] = f; r.nbr[i] = nbr;
         r.geo[i][0] = p0.x; r.geo[i][1] = p0.y; r.geo[i][2] = p0.z;
+#ifndef DMR_TET_EDGES
+#define DMR_TET_EDGES 1
+#endif
+#if DMR_TET_EDGES
+        // (the edge vectors, not the vertices: ray_tri_hit's p1 - p0 and p2 - p0, taken here once per tet and face -- the march
+        // is VALU-bound, profiles/r03/valu_mix_c3.txt, and these were 18 of a step's ~420 instructions)
+        const V3 E1 = p1 - p0, E2 = p2 - p0;
+        r.geo[i][3] = E1.x; r.geo[i][4] = E1.y; r.geo[i][5] = E1.z;
+        r.geo[i][6] = E2.x; r.geo[i][7] = E2.y; r.geo[i][8] = E2.z;
+#else
         r.geo[i][3] = p1.x; r.geo[i][4] = p1.y; r.geo[i][5] = p1.z;
         r.geo[i][6] = p2.x; r.geo[i][7] = p2.y; r.geo[i][8] = p2.z;
+#endif
         r.geo[i][9] = n.x; r.geo[i][10] = n.y; r.geo[i][11] = n.z;
     }
     tetrec[t] = r;
@@ -299,7 +310,11 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     auto test = [&](float4 q0, float4 q1, float4 q2, int e, int behind) {
         const int of = e & TET_FACE_MASK;
         V3 tuv;
+#if DMR_TET_EDGES
+        const bool hit = ray_tri_hit_edges(ro, rd, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}, tuv) && (unsigned)of < (unsigned)p.F;
+#else
         const bool hit = ray_tri_hit(ro, rd, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x}, tuv) && (unsigned)of < (unsigned)p.F;
+#endif
         const V3 n = {q2.y, q2.z, q2.w};
         const float dn0 = dot(n, rd);
         const float dn = e < 0 ? -dn0 : dn0;
