@@ -146,7 +146,7 @@ int check_scene(const dmr_scene* s, bool tet, Dims& d) {
     d.ntiles = s->B * d.gx * d.gy;
     d.BP = (size_t)s->B * s->P; d.BF = (size_t)s->B * s->F; d.npix = (size_t)s->B * s->W * s->H;
     if (tet && s->F > 0 && s->P > 0 && (!s->tets || !s->face_tets || !s->tet_faces)) return fail("tet topology missing");
-    if (tet && s->F >= (1 << 29)) return fail("too many faces for the tet renderer (face ids must fit 29 bits)");
+    if (tet && s->F >= (1 << 28)) return fail("too many faces for the tet renderer (face ids must fit 28 bits)");
     return 0;
 }
 

@@ -36,7 +36,20 @@ static_assert(sizeof(TetColRec) == 64, "TetColRec");
 // now carries the slot its current face has in its current tet, so the step's eleven loads go out together, one level.
 struct alignas(16) TetBlock { int face[4]; int nbr[4]; float geo[4][12]; };
 static_assert(sizeof(TetBlock) == 224, "TetBlock");
+#ifndef DMR_TET_DUP_BIT
+#define DMR_TET_DUP_BIT 1
+#endif
+#if DMR_TET_DUP_BIT
+constexpr int TET_FACE_MASK = 0x0fffffff;  // (check_scene: F < 2^28)
+// bit 28 of a face entry: the same face id sits in another slot of this tet as well (malformed tet_faces).  The march carries
+// the slot of its current face, so the reference's "exactly one of the tet's four faces is the current one" (`cnt != 3`,
+// forward.cu:716-722) is: the slot's entry is the current face and has no duplicate -- one compare per step instead of four
+// masks, four compares and a count, all of the 4.5-cycle kind in a kernel whose VALUs are busy all the time.
+constexpr int TET_FACE_DUP = 0x10000000;
+#else
 constexpr int TET_FACE_MASK = 0x1fffffff;  // (check_scene: F < 2^29)
+constexpr int TET_FACE_DUP = 0;
+#endif
 
 struct TetParams {
     int B, P, F, W, H, gx, gy, r0;
@@ -127,7 +140,9 @@ k_tet_prep_tets(int T, int F, const float* __restrict__ verts, const int* __rest
                 for (int q = 3; q >= 0; q--) if (tet_faces[4 * nbr + q] == f) nslot = q;
             }
             const bool flip = dot(n, center - p0) > 0.0f;
-            f = f | (nslot << 29) | (flip ? (int)0x80000000 : 0);
+            bool dup = false;  // (as the reference counts: any other entry with the same id)
+            for (int q = 0; q < 4; q++) if (q != i && tet_faces[4 * t + q] == f) dup = true;
+            f = f | (nslot << 29) | (flip ? (int)0x80000000 : 0) | (dup ? TET_FACE_DUP : 0);
         }
         r.face[i] = f; r.nbr[i] = nbr;
         r.geo[i][0] = p0.x; r.geo[i][1] = p0.y; r.geo[i][2] = p0.z;
@@ -291,12 +306,18 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     const float4 a0 = g0[0], a1 = g0[1], a2 = g0[2];
     const float4 b0 = g1[0], b1 = g1[1], b2 = g1[2];
     const float4 c0 = g2[0], c1 = g2[1], c2 = g2[2];
+#if DMR_TET_DUP_BIT
+    const int cur_e = s1 ? tr.x : (s2 ? tr.y : (s3 ? tr.z : tr.w));  // the entry of the slot the march carries
+    if ((cur_e & (TET_FACE_MASK | TET_FACE_DUP)) != curr_face) return false;  // the reference's `cnt != 3` (see TET_FACE_DUP)
+    const bool cur_flip = cur_e < 0;
+#else
     const int t0 = tr.x & TET_FACE_MASK, t1 = tr.y & TET_FACE_MASK, t2 = tr.z & TET_FACE_MASK, t3 = tr.w & TET_FACE_MASK;
     const bool m0 = t0 == curr_face, m1 = t1 == curr_face, m2 = t2 == curr_face, m3 = t3 == curr_face;
     if ((int)m0 + (int)m1 + (int)m2 + (int)m3 != 1) return false;  // the reference's `cnt != 3` (then the slot is the match's)
+    const bool cur_flip = (m0 ? tr.x : (m1 ? tr.y : (m2 ? tr.z : tr.w))) < 0;
+#endif
     const int r0e = s1 ? tr.y : tr.x, r1e = s2 ? tr.z : tr.y, r2e = s3 ? tr.w : tr.z;
     const int nb0 = s1 ? nb.y : nb.x, nb1 = s2 ? nb.z : nb.y, nb2 = s3 ? nb.w : nb.z;
-    const bool cur_flip = (m0 ? tr.x : (m1 ? tr.y : (m2 ? tr.z : tr.w))) < 0;
     bool ok = true;
     const float dcur0 = dot(curr_n, rd);  // the current face's unit normal came with the previous step
     const float dcur = cur_flip ? -dcur0 : dcur0;

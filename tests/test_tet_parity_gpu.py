@@ -216,3 +216,39 @@ def test_empty_inputs(hip_device):
         th.cuda.synchronize()
         assert [tuple(x.shape) for x in g] == [(P, 3), (F,)]
         assert all(float(x.abs().sum()) == 0.0 for x in g)
+
+
+def test_malformed_tets_stop_the_march_like_the_reference(oracle, hip_device):
+    """tet_faces with a face listed twice in a tet, and with a face that is not the one its neighbour points back with: the
+    reference's march stops there (`cnt != 3`, forward.cu:716-722; "error cases").  The HIP march decides that from one bit per
+    face entry set when the records are built (TET_FACE_DUP, dmr_tet.hip) -- the topology of every pixel's march must still be
+    the reference's, for the forward and for both backward paths."""
+    from dmesh_renderer_amd import _C
+    m, B, H, W = 5, 1, 112, 128
+    d = scenes.kuhn_tets(m, B, H, W, seed=3, opacity=(0.05, 0.4))
+    tf = d["tet_faces"].clone()
+    T = tf.shape[0]
+    tf[3::11, 1] = tf[3::11, 0]           # the same face in two slots of a tet
+    tf[5::13, 2] = tf[(7 + 5) % T, 0]     # a face of some other tet in the third slot
+    d["tet_faces"] = tf.contiguous()
+    sc = oracle.scene_from_module_inputs(d, H, W)
+    ocolor, odepth, oactive, ost = oracle.tet_forward(sc)
+    args = c_args(d, hip_device, tet=True)
+    gc, gd = upstream_grads(B, H, W)
+    og = oracle.tet_backward(sc, ost, gc.numpy(), gd.numpy())
+    for call in range(2):  # the second call's backward runs on the forward's march sequence
+        out = _C.render_tets(*args, H, W, 0)
+        th.cuda.synchronize()
+        bufs = out[3:7]
+        ex = lambda name, dtype: _C.export(name, args, True, ost.num_rendered, bufs, H, W, dtype).cpu().numpy()
+        for name in ("first_face", "first_tet", "last_face", "last_tet"):
+            np.testing.assert_array_equal(ex(name, th.int32), ost.get(name), err_msg=name)
+        np.testing.assert_array_equal(ex("n_contrib", th.int32).view(np.uint32), ost.get("n_contrib"))
+        np.testing.assert_array_equal(out[2].cpu().numpy(), oactive)
+        assert np.abs(out[0].cpu().numpy() - ocolor).max() <= FWD_TOL
+        g = _C.render_tets_backward(*args, gc.to(hip_device), gd.to(hip_device), *bufs)
+        th.cuda.synchronize()
+        for got, key in zip(g, ("verts_color", "faces_opacity")):
+            assert rel_err(got.cpu().numpy(), og[key]) <= GRAD_TOL, (call, key)
+    stopped = (oactive == 0) & (ost.get("first_face").reshape(oactive.shape) >= 0)
+    assert stopped.any(), "the scene must have marches that stop inside the mesh"
