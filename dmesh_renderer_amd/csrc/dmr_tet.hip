@@ -21,8 +21,20 @@ namespace dmr {
 
 constexpr int FI_CHUNK = 256;
 
+#ifndef DMR_TET_FI_HOIST
+#define DMR_TET_FI_HOIST 1
+#endif
+#if DMR_TET_FI_HOIST
+// A staged face of the first-hit search with everything of ray_tri_hit (cuda_renderer/auxiliary.h:265-296) that does not depend
+// on the ray's direction -- the origin is the same for all pixels of a view: T = o - p0, E1, E2, Q = T x E1, Q . E2 (the
+// numerator of t) -- computed once per staged face with the reference's arithmetic instead of once per (pixel, face): 23 of a
+// test's ~68 instructions in a kernel whose VALUs are busy 91 % of the time (profiles/r03/valu_mix_c3.txt).
+struct alignas(16) HitRec { float T[3], E1[3], E2[3], Q[3]; float qe2, min_depth, max_depth; int face; };
+static_assert(sizeof(HitRec) == 64, "HitRec");
+#else
 struct alignas(16) HitRec { float p0[3], p1[3], p2[3]; float min_depth, max_depth; int face; };
 static_assert(sizeof(HitRec) == 48, "HitRec");
+#endif
 
 struct alignas(16) TetFaceRec { float p0[3], p1[3], p2[3], n[3]; int ft0, ft1; float opacity; int pad; };
 static_assert(sizeof(TetFaceRec) == 64, "TetFaceRec");
@@ -211,6 +223,7 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
 
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
     if (inside) pixel_ray<true>(p.inv_mv + 16 * b, p.inv_proj + 16 * b, px, py, p.W, p.H, ro, rd, *p.seed, (uint64_t)bpix);
+    const V3 view_o = {p.inv_mv[16 * b + 12], p.inv_mv[16 * b + 13], p.inv_mv[16 * b + 14]};  // = ro of every pixel of the view
 
     const int tile = (b * p.gy + ty) * p.gx + tx;
     // (a list beyond the buffer -- only while a size guess is being refuted, the result is redone then -- holds no
@@ -238,9 +251,19 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
             const V3 c = load_v3(p.verts, p.faces[3 * face + 1]);
             const V3 e = load_v3(p.verts, p.faces[3 * face + 2]);
             HitRec& r = s_rec[tid];
+#if DMR_TET_FI_HOIST
+            const V3 hT = view_o - a, hE1 = c - a, hE2 = e - a;
+            const V3 hQ = cross(hT, hE1);
+            r.T[0] = hT.x; r.T[1] = hT.y; r.T[2] = hT.z;
+            r.E1[0] = hE1.x; r.E1[1] = hE1.y; r.E1[2] = hE1.z;
+            r.E2[0] = hE2.x; r.E2[1] = hE2.y; r.E2[2] = hE2.z;
+            r.Q[0] = hQ.x; r.Q[1] = hQ.y; r.Q[2] = hQ.z;
+            r.qe2 = dot(hQ, hE2);
+#else
             r.p0[0] = a.x; r.p0[1] = a.y; r.p0[2] = a.z;
             r.p1[0] = c.x; r.p1[1] = c.y; r.p1[2] = c.z;
             r.p2[0] = e.x; r.p2[1] = e.y; r.p2[2] = e.z;
+#endif
             r.min_depth = key_depth[(int64_t)b * p.F + face];
             r.max_depth = max_depth[(int64_t)b * p.F + face];
             r.face = face;
@@ -250,9 +273,23 @@ k_tet_first_intersect(TetParams p, const float* __restrict__ key_depth, const fl
             const HitRec& r = s_rec[j];
             if (min_T >= 0.0f && r.min_depth > min_T_max_depth) { done = true; continue; }
             V3 tuv;
+#if DMR_TET_FI_HOIST
+            {
+                const V3 E1 = {r.E1[0], r.E1[1], r.E1[2]}, E2 = {r.E2[0], r.E2[1], r.E2[2]};
+                const V3 P = cross(rd, E2);
+                const float denom = dot(P, E1);
+                if (denom == 0.0f) continue;
+                const float inv_denom = 1.0f / denom;
+                tuv.x = r.qe2 * inv_denom;
+                tuv.y = dot(P, {r.T[0], r.T[1], r.T[2]}) * inv_denom;
+                tuv.z = dot({r.Q[0], r.Q[1], r.Q[2]}, rd) * inv_denom;
+                if (!(tuv.x >= 0.0f && tuv.y >= 0.0f && tuv.z >= 0.0f && tuv.y + tuv.z <= 1.0f)) continue;
+            }
+#else
             if (!ray_tri_hit(ro, rd, {r.p0[0], r.p0[1], r.p0[2]}, {r.p1[0], r.p1[1], r.p1[2]},
                              {r.p2[0], r.p2[1], r.p2[2]}, tuv))
                 continue;
+#endif
             if (min_T < 0.0f || tuv.x < min_T) { min_T = tuv.x; min_T_max_depth = r.max_depth; ff = r.face; }
         }
     }
