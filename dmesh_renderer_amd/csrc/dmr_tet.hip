@@ -331,7 +331,7 @@ __device__ __forceinline__ void face_tuv(const TetParams& p, V3 ro, V3 rd, int f
 // backward needs to know of this tet.
 template <bool FWD>
 __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int& curr_face, int& curr_tet, int& curr_slot,
-                                           float& curr_rt, float& curr_iu, float& curr_iv, V3& curr_n, bool* back_amb = nullptr) {
+                                           float& curr_rt, float& curr_iu, float& curr_iv, float& curr_dn, bool* back_amb = nullptr) {
     // The tet's record: header and the three faces other than the current one (whose slot the march carries), all requested
     // at once.  `others` keep the record's order, as the reference's loop over tet_faces does.
     const char* base = reinterpret_cast<const char*>(p.tetrec + curr_tet);
@@ -356,12 +356,12 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     const int r0e = s1 ? tr.y : tr.x, r1e = s2 ? tr.z : tr.y, r2e = s3 ? tr.w : tr.z;
     const int nb0 = s1 ? nb.y : nb.x, nb1 = s2 ? nb.z : nb.y, nb2 = s3 ? nb.w : nb.z;
     bool ok = true;
-    const float dcur0 = dot(curr_n, rd);  // the current face's unit normal came with the previous step
+    const float dcur0 = curr_dn;  // dot(the current face's unit normal, rd): the previous step computed it when it chose the face
     const float dcur = cur_flip ? -dcur0 : dcur0;
     if (FWD ? (dcur >= 0.0f) : (dcur <= 0.0f)) ok = false;
     int nf = -1, ncnt = 0, nt = -1, ns = 0;
     float nrt = 0, niu = 0, niv = 0;
-    V3 nn = {0, 0, 0};
+    float ndn = 0.f;
     bool amb = false;
     // q0..q2: p0, p1, p2, unit normal of the candidate; e: its header entry; behind: the tet on its other side
     // (a face id outside [0, F) -- malformed tet_faces -- never hits)
@@ -377,7 +377,7 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
         const float dn0 = dot(n, rd);
         const float dn = e < 0 ? -dn0 : dn0;
         if (hit && (FWD ? (dn > 0.0f) : (dn < 0.0f))) {
-            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nt = behind; ns = (e >> 29) & 3; nn = n; ncnt++;
+            nf = of; nrt = tuv.x; niu = tuv.y; niv = tuv.z; nt = behind; ns = (e >> 29) & 3; ndn = dn0; ncnt++;
         }
         if (FWD && hit && dn < 0.0f) amb = true;
     };
@@ -386,7 +386,7 @@ __device__ __forceinline__ bool march_step(const TetParams& p, V3 ro, V3 rd, int
     test(c0, c1, c2, r2e, nb2);
     if (ncnt != 1 || !ok) return false;
     if (FWD && back_amb) *back_amb = amb;
-    curr_face = nf; curr_tet = nt; curr_slot = ns; curr_rt = nrt; curr_iu = niu; curr_iv = niv; curr_n = nn;
+    curr_face = nf; curr_tet = nt; curr_slot = ns; curr_rt = nrt; curr_iu = niu; curr_iv = niv; curr_dn = ndn;
     return true;
 }
 
@@ -424,11 +424,13 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
     bool done = false;
     int curr_face = first_face, curr_tet = first_tet;
     float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
-    V3 curr_n = {0, 0, 0};
+    float curr_dn = 0.f;  // dot(curr_face's unit normal before orientation, rd)
     int curr_slot = 0;  // the slot of curr_face in curr_tet's record
     if (first_face == -1 || first_tet == -1) done = true;
     else {
+        V3 curr_n = {0, 0, 0};
         face_tuv(p, ro, rd, first_face, curr_rt, curr_iu, curr_iv, curr_n);
+        curr_dn = dot(curr_n, rd);
         curr_slot = tet_slot_of(p.tetrec, first_tet, first_face);
     }
 
@@ -474,7 +476,7 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         last_face = curr_face;
         last_tet = curr_tet;
         if (curr_tet == -1) { active = true; done = true; }
-        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_n, &back_amb)) done = true;
+        if (!done && !march_step<true>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_dn, &back_amb)) done = true;
     }
     {   // the wave's longest march (is the sequence complete? the next call's estimate)
         const uint32_t steps = wave_max_u32(n_contrib);
@@ -812,9 +814,11 @@ k_tet_backward(TetParams p, int rows, const float* __restrict__ dL_dcolor, const
         int curr_face = last_face, curr_tet = -1, curr_slot = 0;
         float curr_rt = 0.f, curr_iu = 0.f, curr_iv = 0.f;
         V3 curr_n = {0, 0, 0};
+        float curr_dn = 0.f;  // dot(curr_face's unit normal before orientation, rd), carried from step to step (march_step)
         if (!done) {
             curr_tet = p.img.last_tet[(int64_t)b * p.H * p.W + (int64_t)p.W * py + px];
             face_tuv(p, ro, rd, last_face, curr_rt, curr_iu, curr_iv, curr_n);
+            curr_dn = dot(curr_n, rd);
             // step back across the last face (backward.cu:223-232)
             for (int i = 0; i < 2; i++) {
                 const int t = p.face_tets[2 * curr_face + i];
@@ -834,7 +838,7 @@ k_tet_backward(TetParams p, int rows, const float* __restrict__ dL_dcolor, const
                 if (curr_face == first_face) done = true;
                 if (!done) {
                     if (curr_tet == -1) done = true;
-                    else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_n)) done = true;
+                    else if (!march_step<false>(p, ro, rd, curr_face, curr_tet, curr_slot, curr_rt, curr_iu, curr_iv, curr_dn)) done = true;
                 }
             }
             tet_accumulate(p, acc, s_val, lane, act, face, g, v0, v1, v2, dL_dvcolor, dL_dfopacity);
