@@ -465,7 +465,12 @@ k_tet_forward(TetParams p, float* __restrict__ out_color, float* __restrict__ ou
         C = C + tmp_T * opacity * col;
         const V3 pt = ro + (rd * curr_rt);
         const V4 pn = xform4x4(xform4x3(pt, mv), pr);
-        const float pw = 1.0f / clamp_w(pn.w);
+#ifndef DMR_TET_FWD_RCP
+#define DMR_TET_FWD_RCP 1
+#endif
+        // (the hit point's depth decides nothing: 1-ulp reciprocal instead of the IEEE division's ten instructions -- the march is
+        // VALU-bound; out_depth moves by ~1e-7 of its value, the tolerance is 1e-5)
+        const float pw = DMR_TET_FWD_RCP ? __builtin_amdgcn_rcpf(clamp_w(pn.w)) : 1.0f / clamp_w(pn.w);
         D += tmp_T * opacity * (pn.z * pw);
         prev_log_T = log_T;
         if (opacity < 1.0f) log_T += cq3.y;  // logf(1 - opacity), per face (TetColRec)
